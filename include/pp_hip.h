@@ -1,0 +1,215 @@
+/*
+ * pp_hip.h -- C ABI of the MI355X-native planner core (libpphip.so).
+ *
+ * Drop-in boundary for the hot path of lfilipozzi/PathPlanning.
+ * The reference has no FFI of its own: its plugin surface is the C++ abstract
+ * classes StateValidator / PathPlanner plus the pybind11 module.  These entry
+ * points are what those classes call into (see INTEGRATION.md for the binding a
+ * reference maintainer adds).  Each function cites the reference interface it
+ * replaces, paths relative to the reference's planner/src.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (never throws);
+ *     pp_last_error() gives the message of the calling thread's last failure;
+ *   - *_dev functions take DEVICE pointers and only enqueue work on the context's
+ *     stream (no host synchronisation); the others take HOST pointers, copy,
+ *     run and synchronise;
+ *   - poses are 3 contiguous doubles {x, y, theta} exactly like Pose2d
+ *     (geometry/2dplane.h:17-34); grids are row-major, index = row*cols + col,
+ *     row <- x, col <- y (utils/grid.h:87, state_validator/occupancy_map.h:106-117);
+ *   - no torch types, no C++ types, no global state besides the error string.
+ */
+#ifndef PP_HIP_H
+#define PP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_OK 0
+#define PP_ERR_INVALID (-1)
+#define PP_ERR_HIP (-2)
+#define PP_ERR_NO_DEVICE (-3)
+#define PP_ERR_CAPACITY (-4)
+
+typedef struct pp_ctx pp_ctx;         /* one device + one stream */
+typedef struct pp_map pp_map;         /* device-resident map set of one OccupancyMap */
+typedef struct pp_planner pp_planner; /* Hybrid-A* tables + per-query workspaces */
+
+const char* pp_last_error(void);
+int pp_version(void);
+
+/* ---- context ----------------------------------------------------------- */
+/* stream == NULL: the context creates and owns a stream; otherwise it enqueues
+ * on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int pp_ctx_create(int device, void* stream, pp_ctx** out);
+int pp_ctx_destroy(pp_ctx* ctx);
+int pp_ctx_synchronize(pp_ctx* ctx);
+/* HIP-event timer on the context's stream: start, stop -> milliseconds. */
+int pp_ctx_timer_start(pp_ctx* ctx);
+int pp_ctx_timer_stop(pp_ctx* ctx, float* ms);
+int pp_device_count(void);
+
+/* ---- map set ------------------------------------------------------------
+ * Replaces the data members of OccupancyMap (state_validator/occupancy_map.h:122-133),
+ * GVD::ObstacleDistanceMap::m_distance (state_validator/gvd.h:58), GVD::PathCostMap
+ * (gvd.h:111-121) and the StateSpaceSE2 bounds (state_space/state_space.h:60-61). */
+typedef struct pp_map_desc {
+	int32_t rows, cols;
+	float resolution;         /* OccupancyMap::resolution (float) */
+	double grid_origin[2];    /* m_worldGridOrigin */
+	double local_origin[2];   /* m_localOrigin */
+	double lower[3], upper[3]; /* StateSpaceSE2::bounds */
+} pp_map_desc;
+
+int pp_map_create(pp_ctx* ctx, const pp_map_desc* desc, pp_map** out);
+int pp_map_destroy(pp_map* map);
+/* int32 squared distances to the nearest obstacle, INT_MAX = none (gvd.cpp:21). */
+int pp_map_upload_dist2(pp_map* map, const int32_t* d2_host);
+/* int32 occupancy, >= 0 occupied, < 0 free (obstacle_list_occupancy_map.cpp:63-69). */
+int pp_map_upload_occupancy(pp_map* map, const int32_t* occ_host);
+/* float Voronoi-field potential, GVD::GetPathCost (gvd.h:160-162). */
+int pp_map_upload_path_cost(pp_map* map, const float* cost_host);
+/* StateValidatorOccupancyMap::minSafeRadius / minPathInterpolationDistance
+ * (state_validator/state_validator_occupancy_map.h:27-28). */
+int pp_map_set_validator(pp_map* map, float min_safe_radius, float min_path_interpolation_distance);
+/* Copies the derived float distance grid back (tests): (float)(sqrt((double)d2) * resolution), gvd.h:38. */
+int pp_map_download_distance(pp_map* map, float* dist_host);
+
+/* ---- a1: StateValidatorOccupancyMap::IsStateValid -------------------------
+ * (state_validator/state_validator_occupancy_map.cpp:15-26), batched. */
+int pp_check_states(pp_map* map, int64_t n, const double* poses_host, uint8_t* valid_host);
+int pp_check_states_dev(pp_map* map, int64_t n, const double* poses_dev, uint8_t* valid_dev);
+/* Fused microbench form ("M1 fused"): poses are generated in-kernel from a
+ * counter-based hash, only a per-block count of valid poses leaves the kernel. */
+int pp_check_states_fused_dev(pp_map* map, int64_t n, uint64_t seed, uint64_t* valid_count_dev);
+
+/* ---- a2+a3: IsPathValid over constant-steer arcs --------------------------
+ * (state_validator_occupancy_map.cpp:28-71 with paths/path_constant_steer.cpp:11-20 and
+ * models/kinematic_bicycle_model.cpp:5-32).  curvature = cos(beta)*tan(steer)/wheelbase
+ * (kinematic_bicycle_model.cpp:17), computed by the caller with libm. direction: 0 fwd, 1 bwd. */
+int pp_check_arcs_dev(pp_map* map, int64_t n, const double* from_dev, const double* curvature_dev, const double* length_dev,
+	const int32_t* direction_dev, uint8_t* valid_dev, float* last_ratio_dev);
+int pp_check_arcs(pp_map* map, int64_t n, const double* from_host, const double* curvature_host, const double* length_host,
+	const int32_t* direction_host, uint8_t* valid_host, float* last_ratio_host);
+/* R2 segments (paths/path_r2.cpp) against the same validator with theta = 0: the
+ * RRT / RRT* edge check on an occupancy map. */
+int pp_check_segments_dev(pp_map* map, int64_t n, const double* from_xy_dev, const double* to_xy_dev, uint8_t* valid_dev);
+int pp_check_segments(pp_map* map, int64_t n, const double* from_xy_host, const double* to_xy_host, uint8_t* valid_host);
+
+/* ---- a4: HybridAStar::StatePropagator::GetConstantSteerChild ---------------
+ * (algo/hybrid_a_star.cpp:111-147, 41-48, 93-109; hybrid_a_star.h:104-111).
+ * One child per (parent, primitive), reference order: primitive p = 2*deltaIndex + dir. */
+typedef struct pp_hybrid_params {
+	double wheelbase;                /* SearchParameters::wheelbase */
+	double min_turning_radius;
+	double direction_switching_cost;
+	double reverse_cost_multiplier;
+	double forward_cost_multiplier;
+	double voronoi_cost_multiplier;
+	uint32_t num_generated_motion;
+	double spatial_resolution;
+	double angular_resolution;
+	/* reference-behaviour switches; 1 = as the Release build behaves */
+	int32_t heading_alias;    /* Q6 */
+	int32_t negative_k_read;  /* Q7 */
+} pp_hybrid_params;
+
+int pp_rollout_children_dev(pp_map* map, const pp_hybrid_params* params, int32_t n_primitives, const double* curvature_host,
+	const int32_t* direction_host, int64_t n_parents, const double* parents_dev, uint8_t* valid_dev, double* pose_dev, int32_t* key_dev,
+	double* cost_dev, double* length_dev);
+int pp_rollout_children(pp_map* map, const pp_hybrid_params* params, int32_t n_primitives, const double* curvature_host,
+	const int32_t* direction_host, int64_t n_parents, const double* parents_host, uint8_t* valid_host, double* pose_host, int32_t* key_host,
+	double* cost_host, double* length_host);
+
+/* ---- a6: ReedsShepp::Solver::GetOptimalPath -------------------------------
+ * (geometry/reeds_shepp.cpp:654-683), one (from, to) pair per element.
+ * word: PathWords index or -1; tuv: the three parameters; cost: float as the
+ * reference compares it; seg_length: normalised length. */
+int pp_rs_solve_dev(pp_ctx* ctx, int64_t n, const double* from_dev, const double* to_dev, double min_turning_radius, float reverse_cost,
+	float forward_cost, float switch_cost, int32_t* word_dev, double* tuv_dev, float* cost_dev, double* seg_length_dev);
+int pp_rs_solve(pp_ctx* ctx, int64_t n, const double* from_host, const double* to_host, double min_turning_radius, float reverse_cost,
+	float forward_cost, float switch_cost, int32_t* word_host, double* tuv_host, float* cost_host, double* seg_length_host);
+
+/* ---- a10: NonHolonomicHeuristic::Build (algo/heuristics.cpp:36-76) ---------
+ * dims = {nX, nY, nAngular}; table[(i*nY + j)*nAngular + k]. */
+int pp_nonholo_dims(const double lower[3], const double upper[3], const pp_hybrid_params* params, int32_t dims[3], double offsets[2]);
+int pp_nonholo_build_dev(pp_ctx* ctx, const double lower[3], const double upper[3], const pp_hybrid_params* params, double* table_dev);
+int pp_nonholo_build(pp_ctx* ctx, const double lower[3], const double upper[3], const pp_hybrid_params* params, double* table_host);
+
+/* ---- a8: ObstaclesHeuristic::Update (algo/heuristics.cpp:106-153) ----------
+ * One wavefront per goal; cost_dev is [n_goals][rows*cols] float, +inf where the
+ * reference leaves the cell unexplored.  Exact reference order (first discovery,
+ * no relaxation, LIFO ties).  goal_xy: world positions. */
+int pp_obstacle_heuristic_dev(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev);
+int pp_obstacle_heuristic(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_host);
+/* bytes of scratch pp_obstacle_heuristic_dev keeps per concurrently running goal */
+int64_t pp_obstacle_heuristic_workspace_bytes(pp_map* map);
+
+/* ---- a5/a9/a11: HybridAStar graph search, batched --------------------------
+ * (algo/hybrid_a_star.cpp:59-91,149-173,237-257; algo/a_star.h:326-427;
+ * algo/heuristics.cpp:78-95,155-165; utils/frontier.h).  One independent query per
+ * (start, goal, seed); seed reseeds the query's own mt19937_64 (utils/random.h). */
+int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, pp_planner** out);
+int pp_planner_destroy(pp_planner* planner);
+/* Uses a table built elsewhere (host pointer), or builds it on the device when NULL. */
+int pp_planner_set_nonholo_table(pp_planner* planner, const double* table_host);
+int pp_planner_get_nonholo_table(pp_planner* planner, double* table_host);
+int pp_planner_num_primitives(pp_planner* planner);
+
+typedef struct pp_query_result {
+	int32_t status;        /* 0 = Success, -1 = Failure (algo/path_planner.h:9-12), -4 = node capacity exceeded */
+	int32_t n_expanded;    /* expansions (frontier pops that were expanded) */
+	int32_t n_nodes;       /* nodes created */
+	int32_t n_path;        /* poses on the solution path (root..goal) */
+	double cost;           /* GetGraphSearchOptimalCost */
+	int32_t n_rng_draws;
+	int32_t n_rs_attempts;
+	int64_t n_state_checks;
+	int64_t n_path_checks;
+} pp_query_result;
+
+/* Runs the batch (obstacle heuristic + graph search per query).  All pointers host. */
+int pp_planner_search_batch(pp_planner* planner, int32_t n_queries, const double* starts_host, const double* goals_host,
+	const uint64_t* seeds_host, pp_query_result* results_host);
+/* Same, inputs already resident (starts/goals/seeds device pointers); results stay on the device until fetched. */
+int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const double* starts_dev, const double* goals_dev,
+	const uint64_t* seeds_dev);
+int pp_planner_fetch_results(pp_planner* planner, int32_t n_queries, pp_query_result* results_host);
+/* Solution path of query q: poses (3*n_path doubles), per-node action kind (0 root, 1 arc, 2 Reeds-Shepp),
+ * primitive index (arc) or RS word, arc length; expanded: cells in expansion order (3*n_expanded ints). Any pointer may be NULL. */
+int pp_planner_get_path(pp_planner* planner, int32_t q, double* poses_host, int32_t* kind_host, int32_t* prim_host, double* length_host,
+	double* tuv_host);
+int pp_planner_get_expanded(pp_planner* planner, int32_t q, int32_t* cells_host);
+/* last batch: milliseconds spent in the wavefront kernel and in the search kernel (HIP events) */
+int pp_planner_last_timings(pp_planner* planner, float* wavefront_ms, float* search_ms);
+
+/* ---- a14: Tree::GetNearestNodes (utils/tree.h:73-116; flann exact kNN) ------
+ * points/queries: {x, y} doubles; idx/d2: [n_queries][k], ascending squared L2,
+ * ties -> lower point index; slots beyond n_points hold -1 / +inf. */
+int pp_knn_dev(pp_ctx* ctx, int64_t n_points, const double* points_dev, int64_t n_queries, const double* queries_dev, int32_t k,
+	int32_t* idx_dev, double* d2_dev);
+int pp_knn(pp_ctx* ctx, int64_t n_points, const double* points_host, int64_t n_queries, const double* queries_host, int32_t k,
+	int32_t* idx_host, double* d2_host);
+
+/* ---- a13: RRT / RRT* (algo/rrt.h:55-95, algo/rrt_star.h:53-112) ------------
+ * Host loop owning the RNG + device kNN / edge checks.  map == NULL: free space
+ * (StateValidatorFree).  params = {maxIteration, maxNumberTreeNode, maxConnectionDistance, goalBias}. */
+typedef struct pp_rrt_result {
+	int32_t status;
+	int32_t n_nodes;
+	int32_t n_path;
+	int64_t iterations, n_knn_queries, n_edge_checks;
+} pp_rrt_result;
+typedef struct pp_rrt pp_rrt;
+int pp_rrt_run(pp_ctx* ctx, pp_map* map, const double lower[2], const double upper[2], const double params[4], const double init[2],
+	const double goal[2], uint64_t seed, int32_t star, pp_rrt** out, pp_rrt_result* result);
+int pp_rrt_get(pp_rrt* r, double* nodes_xy, int32_t* parents, double* costs, double* path_xy);
+int pp_rrt_destroy(pp_rrt* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PP_HIP_H */

@@ -1,0 +1,243 @@
+// Device-side restatement of the per-pose / per-path arithmetic of the hot path.
+// gfx950 only.  Built with -ffp-contract=off: expression order and the
+// float/double mix follow the reference line by line because discrete outputs
+// (cells, heading bins, validity, expansion order) must match it bit for bit.
+//
+// Reference files (relative to planner/src) are cited per function.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ppd {
+
+#define PPD_INLINE __device__ __forceinline__
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kPi2 = 1.57079632679489661923;
+
+struct Pose {
+	double x, y, t;
+};
+
+/// Device view of one map set (filled by pp_map_*).
+struct MapView {
+	int rows, cols;
+	float res;              // OccupancyMap::resolution
+	double gx, gy;          // m_worldGridOrigin
+	double lox, loy;        // m_localOrigin
+	double lbx, lby, lbt;   // StateSpaceSE2 bounds
+	double ubx, uby, ubt;
+	float minSafeRadius;    // StateValidatorOccupancyMap::minSafeRadius
+	float minInterp;        // ...::minPathInterpolationDistance
+	const float* dist;      // (float)(sqrt((double)d2) * res): GetDistanceToNearestObstacle, gvd.h:38
+	const float* pathcost;  // GVD::PathCostMap
+	const uint8_t* occ8;    // 1 = occupied
+};
+
+/// geometry/2dplane.h:36-45
+PPD_INLINE double wrap_theta(double theta)
+{
+	double t = theta;
+	// The reference loops forever on +-inf / astronomically large angles; a GPU wave must not.
+	// Beyond 1e4 rad fold with fmod first (degenerate inputs only; NaN falls through unchanged).
+	if (fabs(t) > 1.0e4)
+		t = fmod(t, 2 * kPi);
+	while (t > kPi)
+		t -= 2 * kPi;
+	while (t < -kPi)
+		t += 2 * kPi;
+	return t;
+}
+
+/// static_cast<int>(double) as x86 cvttsd2si does it for the reference build:
+/// out-of-range and NaN give INT_MIN (the GPU conversion saturates / gives 0).
+PPD_INLINE int trunc_to_int(double v)
+{
+	if (!(v > -2147483649.0 && v < 2147483648.0))
+		return (int)0x80000000;
+	return (int)v;
+}
+
+/// OccupancyMap::WorldPositionToGridCell(bounded = false), occupancy_map.h:106-117,180-183
+PPD_INLINE void world_to_cell(const MapView& m, double x, double y, int& row, int& col)
+{
+	row = trunc_to_int((x - m.gx) / (double)m.res);
+	col = trunc_to_int((y - m.gy) / (double)m.res);
+}
+
+PPD_INLINE bool inside_map(const MapView& m, int row, int col)
+{
+	return row >= 0 && row < m.rows && col >= 0 && col < m.cols; // occupancy_map.cpp:27-30
+}
+
+/// StateValidatorOccupancyMap::IsStateValid, state_validator_occupancy_map.cpp:15-26.
+/// On success also returns the cell's obstacle distance (re-read by IsPathValid).
+PPD_INLINE bool is_state_valid(const MapView& m, double x, double y, double theta, float& distance)
+{
+	const double lx = x - m.lox, ly = y - m.loy;
+	const double lt = wrap_theta(theta); // Pose2d constructor of `localState`
+	int row, col;
+	world_to_cell(m, x, y, row, col);
+	// StateSpaceSE2::ValidateBounds, state_space_se2.cpp:15-25
+	if (lx < m.lbx || lx > m.ubx)
+		return false;
+	if (ly < m.lby || ly > m.uby)
+		return false;
+	if (lt < m.lbt || lt > m.ubt)
+		return false;
+	if (!inside_map(m, row, col))
+		return false;
+	distance = m.dist[(size_t)row * m.cols + col];
+	return distance >= m.minSafeRadius;
+}
+
+/// KinematicBicycleModel::ConstantSteer with rearToCenter = 0 (beta = 0, cos(beta) = 1),
+/// models/kinematic_bicycle_model.cpp:5-32.  `kappa` = DthetaDdist (host libm),
+/// `dist` already carries the direction sign.  theta is not wrapped.
+PPD_INLINE Pose constant_steer(const Pose& from, double kappa, double dist)
+{
+	Pose to = from;
+	if (fabs(kappa) > 1e-9) {
+		to.t += dist * kappa;
+		to.x += 1 / kappa * (sin(to.t) - sin(from.t));
+		to.y += 1 / kappa * (-cos(to.t) + cos(from.t));
+	} else {
+		to.x += dist * cos(from.t);
+		to.y += dist * sin(from.t);
+	}
+	return to;
+}
+
+/// A constant-steer arc: PathConstantSteer, paths/path_constant_steer.cpp:5-25
+struct Arc {
+	Pose init;
+	double kappa;
+	double length;
+	int backward; // 1 = Direction::Backward
+	PPD_INLINE Pose interpolate(double ratio) const
+	{
+		double d = length * ratio;
+		if (backward)
+			d = -d;
+		return constant_steer(init, kappa, d);
+	}
+};
+
+/// An R2 segment seen as an SE2 path with theta = 0 (paths/path_r2.cpp:11-16)
+struct Segment {
+	double x0, y0, x1, y1;
+	double length;
+	PPD_INLINE Pose interpolate(double ratio) const
+	{
+		Pose p;
+		p.x = (1 - ratio) * x0 + ratio * x1;
+		p.y = (1 - ratio) * y0 + ratio * y1;
+		p.t = 0.0;
+		return p;
+	}
+};
+
+PPD_INLINE float fmin4(double a, double b, double c, double d)
+{
+	// std::min({a, b, c, d}) on doubles, converted to float (state_validator_occupancy_map.cpp:54-59)
+	double r = a;
+	if (b < r)
+		r = b;
+	if (c < r)
+		r = c;
+	if (d < r)
+		r = d;
+	return (float)r;
+}
+
+/// StateValidatorOccupancyMap::IsPathValid, state_validator_occupancy_map.cpp:28-71.
+/// `checks` counts IsStateValid calls.
+template <typename PathT>
+PPD_INLINE bool is_path_valid(const MapView& m, const PathT& path, const Pose& init, float& last, int& checks)
+{
+	const double pathLength = path.length;
+	float distance = 0.0f;
+	if (pathLength == 0.0) {
+		last = 1.0f;
+		checks++;
+		return is_state_valid(m, init.x, init.y, init.t, distance);
+	}
+	double lastValidLength = 0.0;
+	double length = 0.0;
+	while (length < pathLength) {
+		// the reference spins forever when minPathInterpolationDistance <= 0 stalls the march;
+		// every wave must drain, so give up (invalid) after 2^22 samples
+		if (checks > (1 << 22)) {
+			last = (float)(lastValidLength / pathLength);
+			return false;
+		}
+		Pose s = path.interpolate(length / pathLength);
+		checks++;
+		if (!is_state_valid(m, s.x, s.y, s.t, distance)) {
+			last = (float)(lastValidLength / pathLength);
+			return false;
+		}
+		lastValidLength = length;
+		float distToMapBorder = fmin4(s.x - m.lbx, m.ubx - s.x, s.y - m.lby, m.uby - s.y);
+		float deltaLength = distance - m.minSafeRadius;
+		deltaLength = fminf(deltaLength, distToMapBorder);
+		length += (double)fmaxf(deltaLength, m.minInterp);
+	}
+	last = 1.0f;
+	return true;
+}
+
+/// HybridAStar::StatePropagator::GetVoronoiCost, algo/hybrid_a_star.cpp:93-109.
+/// The reference overwrites (`=`, not `+=`) the cost at every sample, so only the LAST
+/// sample survives (Appendix A Q8); it is then multiplied by the diagonal resolution (float).
+/// The sample lengths are reproduced by the same repeated double += float accumulation, but
+/// only the last one is interpolated and looked up (the earlier reads have no effect).
+template <typename PathT>
+PPD_INLINE double voronoi_cost(const MapView& m, const PathT& path, float interpLength, double voronoiCostMultiplier)
+{
+	float voronoiCost = 0.0f;
+	const double pathLength = path.length;
+	if (0.0 < pathLength) {
+		double lastLength = 0.0;
+		if (interpLength > 0.0f)
+			for (double length = 0.0; length < pathLength; length += (double)interpLength) {
+				if (length == lastLength && length != 0.0)
+					break; // increment below one ulp of length: the reference would never terminate
+				lastLength = length;
+			}
+		Pose p = path.interpolate(lastLength / pathLength);
+		int row, col;
+		world_to_cell(m, p.x, p.y, row, col);
+		// the reference does not bounds-check (assert compiled out); clamp for memory safety
+		row = min(max(row, 0), m.rows - 1);
+		col = min(max(col, 0), m.cols - 1);
+		voronoiCost = m.pathcost[(size_t)row * m.cols + col];
+	}
+	voronoiCost *= interpLength;
+	return voronoiCostMultiplier * (double)voronoiCost;
+}
+
+/// Pose2<int>::WrapTheta instantiated from the generic template (geometry/2dplane.h:36-45,
+/// T = int): SURVEY Appendix A Q6.
+PPD_INLINE int alias_heading_bin(int theta)
+{
+	int t = theta;
+	while ((double)t > kPi)
+		t = (int)((double)t - 2 * kPi);
+	while ((double)t < -kPi)
+		t = (int)((double)t + 2 * kPi);
+	return t;
+}
+
+/// HybridAStar::StatePropagator::DiscretizePose, algo/hybrid_a_star.h:104-111
+PPD_INLINE void discretize_pose(const Pose& p, double spatialRes, double angularRes, int headingAlias, int& ix, int& iy, int& it)
+{
+	ix = trunc_to_int(p.x / spatialRes);
+	iy = trunc_to_int(p.y / spatialRes);
+	it = trunc_to_int(wrap_theta(p.t) / angularRes);
+	if (headingAlias)
+		it = alias_heading_bin(it);
+}
+
+} // namespace ppd

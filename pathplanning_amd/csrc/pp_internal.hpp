@@ -1,0 +1,89 @@
+// Internal host-side declarations shared by the .hip translation units of libpphip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pp_hip.h"
+#include "pp_device.hpp"
+
+namespace pph {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define PP_HIP_TRY(expr)                       \
+	do {                                       \
+		hipError_t _e = (expr);                \
+		if (_e != hipSuccess)                  \
+			return pph::hip_fail(_e, #expr);   \
+	} while (0)
+
+constexpr int kMaxPrimitives = 128;
+struct PrimTable {
+	int n;
+	double kappa[kMaxPrimitives];
+	int8_t backward[kMaxPrimitives];
+};
+
+struct RolloutParams {
+	double arcLength;        // 1.5 * spatialResolution (hybrid_a_star.cpp:115)
+	double spatialRes, angularRes;
+	double forwardMult, reverseMult, voronoiMult;
+	float voroDiagRes;       // (float)(resolution * sqrt(2.0)), hybrid_a_star.cpp:38
+	int headingAlias;
+};
+
+struct NonHoloDesc {
+	int nx, ny, na;
+	double spatialRes, angularRes, offX, offY;
+	double rmin;
+	float reverseCost, forwardCost, switchCost;
+	double minMult; // min(reverse, forward) as doubles (heuristics.cpp:90)
+	int negativeKRead;
+};
+
+// ---- launchers (pp_kernels_basic.hip) ------------------------------------
+hipError_t launch_d2_to_distance(hipStream_t s, const int32_t* d2, float* dist, int64_t n, float res);
+hipError_t launch_occ_to_u8(hipStream_t s, const int32_t* occ, uint8_t* occ8, int64_t n);
+hipError_t launch_check_states(hipStream_t s, const ppd::MapView& m, int64_t n, const double* poses, uint8_t* valid);
+hipError_t launch_check_states_fused(hipStream_t s, const ppd::MapView& m, int64_t n, uint64_t seed, uint64_t* count);
+hipError_t launch_check_arcs(hipStream_t s, const ppd::MapView& m, int64_t n, const double* from, const double* kappa, const double* length, const int32_t* dir,
+	uint8_t* valid, float* last);
+hipError_t launch_check_segments(hipStream_t s, const ppd::MapView& m, int64_t n, const double* from, const double* to, uint8_t* valid);
+hipError_t launch_rollout(hipStream_t s, const ppd::MapView& m, const RolloutParams& rp, const PrimTable& prims, int64_t nParents, const double* parents,
+	uint8_t* valid, double* pose, int32_t* key, double* cost, double* length);
+hipError_t launch_rs_solve(hipStream_t s, int64_t n, const double* from, const double* to, double rmin, float rev, float fwd, float sw, int32_t* word,
+	double* tuv, float* cost, double* segLength);
+hipError_t launch_nonholo_build(hipStream_t s, const NonHoloDesc& d, double* table);
+hipError_t launch_knn(hipStream_t s, int64_t nPoints, const double* pts, int64_t nQueries, const double* q, int k, int32_t* idx, double* d2);
+
+// ---- wavefront (pp_wavefront.hip) -----------------------------------------
+struct WavefrontWorkspace;
+int64_t wavefront_workspace_bytes(int rows, int cols);
+/// Runs nGoals wavefronts; goalCells[g] = row*cols+col or -1 (goal outside the map -> field stays +inf).
+hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
+	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev);
+
+} // namespace pph
+
+struct pp_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	bool ownsStream = false;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct pp_map {
+	pp_ctx* ctx = nullptr;
+	pp_map_desc desc {};
+	float minSafeRadius = 1.0f, minInterp = 0.1f;
+	int32_t* d2 = nullptr;
+	float* dist = nullptr;
+	float* pathcost = nullptr;
+	uint8_t* occ8 = nullptr;
+	ppd::MapView view() const;
+	size_t cells() const { return (size_t)desc.rows * desc.cols; }
+};

@@ -1,0 +1,378 @@
+// Batched per-pose / per-path kernels of the hot path (gfx950):
+//   check_states      a1  IsStateValid                (HBM-bound stream + cached gather)
+//   check_arcs        a2+a3 IsPathValid over constant-steer arcs
+//   check_segments    a2  IsPathValid over R2 segments (RRT edge check)
+//   rollout_children  a4  GetConstantSteerChild for parents x primitives
+//   rs_solve          a6  Reeds-Shepp GetOptimalPath
+//   nonholo_build     a10 NonHolonomicHeuristic::Build
+//   knn               a14 exact k nearest neighbours (flann replacement)
+#include "pp_internal.hpp"
+#include "pp_rs_device.hpp"
+
+using namespace ppd;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(int64_t n, int block, int maxBlocks = 256 * 16)
+{
+	int64_t b = (n + block - 1) / block;
+	if (b < 1)
+		b = 1;
+	if (b > maxBlocks)
+		b = maxBlocks;
+	return (int)b;
+}
+
+// ---------------------------------------------------------------- map prep --
+__global__ void k_d2_to_distance(const int32_t* __restrict__ d2, float* __restrict__ dist, int64_t n, float res)
+{
+	// GVD::ObstacleDistanceMap::GetDistanceToNearestObstacle, gvd.h:38:
+	// std::sqrt(int) -> double sqrt; times the float resolution in double; returned as float.
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+		dist[i] = (float)(sqrt((double)d2[i]) * (double)res);
+}
+
+__global__ void k_occ_to_u8(const int32_t* __restrict__ occ, uint8_t* __restrict__ occ8, int64_t n)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+		occ8[i] = occ[i] >= 0 ? 1 : 0; // obstacle_list_occupancy_map.cpp:63-69
+}
+
+// ------------------------------------------------------------ check_states --
+// One pose per thread.  A block stages its 256 poses (6 KiB, contiguous in the
+// Pose2d AoS layout) through LDS with 16-byte coalesced loads, so HBM sees whole
+// lines once; the distance grid is a cached gather (4 MiB at 1024^2: L2 resident).
+__global__ void __launch_bounds__(kBlock) k_check_states(MapView m, int64_t n, const double* __restrict__ poses, uint8_t* __restrict__ valid, int aligned16)
+{
+	__shared__ double2 tile[kBlock * 3 / 2];
+	const int64_t nTiles = (n + kBlock - 1) / kBlock;
+	for (int64_t tileIdx = blockIdx.x; tileIdx < nTiles; tileIdx += gridDim.x) {
+		const int64_t base = tileIdx * kBlock;
+		const int count = (int)min((int64_t)kBlock, n - base);
+		const double* src = poses + base * 3;
+		const int nd = count * 3; // doubles in this tile
+		if (count == kBlock && aligned16) {
+			const double2* src2 = reinterpret_cast<const double2*>(src); // base*24 bytes is 16-byte aligned
+			tile[threadIdx.x] = src2[threadIdx.x];
+			if (threadIdx.x < kBlock / 2)
+				tile[kBlock + threadIdx.x] = src2[kBlock + threadIdx.x];
+		} else {
+			double* t = reinterpret_cast<double*>(tile);
+			for (int i = threadIdx.x; i < nd; i += kBlock)
+				t[i] = src[i];
+		}
+		__syncthreads();
+		if ((int)threadIdx.x < count) {
+			const double* t = reinterpret_cast<const double*>(tile) + 3 * threadIdx.x;
+			float d;
+			valid[base + threadIdx.x] = is_state_valid(m, t[0], t[1], t[2], d) ? 1 : 0;
+		}
+		__syncthreads();
+	}
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+	x += 0x9E3779B97F4A7C15ull;
+	x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+	return x ^ (x >> 31);
+}
+__device__ __forceinline__ double u01(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+
+// Fused form: pose i = lb + (ub - lb) * u01(splitmix64(seed + 3i + c)); only a count leaves.
+__global__ void __launch_bounds__(kBlock) k_check_states_fused(MapView m, int64_t n, uint64_t seed, unsigned long long* __restrict__ count)
+{
+	unsigned long long local = 0;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const uint64_t k = seed + 3ull * (uint64_t)i;
+		double x = m.lbx + (m.ubx - m.lbx) * u01(splitmix64(k));
+		double y = m.lby + (m.uby - m.lby) * u01(splitmix64(k + 1));
+		double t = m.lbt + (m.ubt - m.lbt) * u01(splitmix64(k + 2));
+		float d;
+		local += is_state_valid(m, x, y, t, d) ? 1 : 0;
+	}
+	// wave reduce (64 lanes), then one atomic per wave
+	for (int off = 32; off > 0; off >>= 1)
+		local += __shfl_down(local, off, 64);
+	if ((threadIdx.x & 63) == 0 && local)
+		atomicAdd(count, local);
+}
+
+// -------------------------------------------------------------- check_arcs --
+__global__ void __launch_bounds__(kBlock) k_check_arcs(MapView m, int64_t n, const double* __restrict__ from, const double* __restrict__ kappa,
+	const double* __restrict__ length, const int32_t* __restrict__ dir, uint8_t* __restrict__ valid, float* __restrict__ last)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		Arc a;
+		a.init = { from[3 * i], from[3 * i + 1], from[3 * i + 2] };
+		a.kappa = kappa[i];
+		a.length = length[i];
+		a.backward = dir[i] == 1;
+		float l = -1.0f;
+		int checks = 0;
+		bool ok = is_path_valid(m, a, a.init, l, checks);
+		valid[i] = ok ? 1 : 0;
+		if (last)
+			last[i] = l;
+	}
+}
+
+__global__ void __launch_bounds__(kBlock) k_check_segments(MapView m, int64_t n, const double* __restrict__ from, const double* __restrict__ to,
+	uint8_t* __restrict__ valid)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		Segment sg;
+		sg.x0 = from[2 * i];
+		sg.y0 = from[2 * i + 1];
+		sg.x1 = to[2 * i];
+		sg.y1 = to[2 * i + 1];
+		const double dx = sg.x1 - sg.x0, dy = sg.y1 - sg.y0;
+		sg.length = sqrt(dx * dx + dy * dy); // PathR2 ctor: (to - from).norm(), paths/path_r2.cpp:5-9
+		Pose init = { sg.x0, sg.y0, 0.0 };
+		float l;
+		int checks = 0;
+		valid[i] = is_path_valid(m, sg, init, l, checks) ? 1 : 0;
+	}
+}
+
+// -------------------------------------------------------- rollout_children --
+// thread = (parent, primitive).  GetConstantSteerChild, algo/hybrid_a_star.cpp:111-147.
+__global__ void __launch_bounds__(kBlock) k_rollout(MapView m, pph::RolloutParams rp, pph::PrimTable prims, int64_t nParents, const double* __restrict__ parents,
+	uint8_t* __restrict__ valid, double* __restrict__ pose, int32_t* __restrict__ key, double* __restrict__ cost, double* __restrict__ lengthOut)
+{
+	const int P = prims.n;
+	const int64_t total = nParents * P;
+	for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t parent = idx / P;
+		const int prim = (int)(idx - parent * P);
+		Arc a;
+		a.init = { parents[3 * parent], parents[3 * parent + 1], parents[3 * parent + 2] };
+		a.kappa = prims.kappa[prim];
+		a.length = rp.arcLength;
+		a.backward = prims.backward[prim];
+		int pix, piy, pit;
+		discretize_pose(a.init, rp.spatialRes, rp.angularRes, rp.headingAlias, pix, piy, pit);
+		Pose child = a.interpolate(1.0);
+		int ix, iy, it;
+		discretize_pose(child, rp.spatialRes, rp.angularRes, rp.headingAlias, ix, iy, it);
+		float lastValidRatio;
+		int checks = 0;
+		bool ok = true;
+		if (!is_path_valid(m, a, a.init, lastValidRatio, checks)) {
+			// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
+			child = a.interpolate((double)lastValidRatio);
+			a.length *= (double)lastValidRatio;
+			discretize_pose(child, rp.spatialRes, rp.angularRes, rp.headingAlias, ix, iy, it);
+			if (ix == pix && iy == piy && it == pit)
+				ok = false;
+		}
+		double c = 0.0;
+		if (ok) {
+			double pathCost = (a.backward ? rp.reverseMult : rp.forwardMult) * a.length;
+			double switchingCost = 0.0; // hybrid_a_star.cpp:142 compares a direction with itself
+			double voro = voronoi_cost(m, a, rp.voroDiagRes, rp.voronoiMult);
+			c = pathCost + switchingCost + voro;
+		}
+		valid[idx] = ok ? 1 : 0;
+		pose[3 * idx] = child.x;
+		pose[3 * idx + 1] = child.y;
+		pose[3 * idx + 2] = child.t;
+		key[3 * idx] = ix;
+		key[3 * idx + 1] = iy;
+		key[3 * idx + 2] = it;
+		cost[idx] = c;
+		lengthOut[idx] = ok ? a.length : 0.0;
+	}
+}
+
+// ---------------------------------------------------------------- rs_solve --
+__global__ void __launch_bounds__(kBlock) k_rs_solve(int64_t n, const double* __restrict__ from, const double* __restrict__ to, double rmin, float rev, float fwd,
+	float sw, int32_t* __restrict__ word, double* __restrict__ tuv, float* __restrict__ cost, double* __restrict__ segLength)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		Pose a = { from[3 * i], from[3 * i + 1], from[3 * i + 2] };
+		Pose b = { to[3 * i], to[3 * i + 1], to[3 * i + 2] };
+		double t, u, v, sl;
+		float c;
+		int w = rs::optimal_word(a, b, rmin, rev, fwd, sw, t, u, v, c, sl);
+		word[i] = w;
+		if (tuv) {
+			tuv[3 * i] = t;
+			tuv[3 * i + 1] = u;
+			tuv[3 * i + 2] = v;
+		}
+		if (cost)
+			cost[i] = c;
+		if (segLength)
+			segLength[i] = sl;
+	}
+}
+
+// ----------------------------------------------------------- nonholo_build --
+// NonHolonomicHeuristic::Build, algo/heuristics.cpp:62-73: entry (i, j, k) = float cost of the
+// optimal RS path from (i*res - offX, j*res - offY, k*angRes) to the origin.
+__global__ void __launch_bounds__(kBlock) k_nonholo_build(pph::NonHoloDesc d, double* __restrict__ table)
+{
+	const int64_t total = (int64_t)d.nx * d.ny * d.na;
+	for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+		const int k = (int)(idx % d.na);
+		const int64_t ij = idx / d.na;
+		const int j = (int)(ij % d.ny);
+		const int i = (int)(ij / d.ny);
+		Pose p;
+		p.x = i * d.spatialRes - d.offX;
+		p.y = j * d.spatialRes - d.offY;
+		p.t = wrap_theta(k * d.angularRes); // Pose2d constructor
+		Pose g = { 0.0, 0.0, 0.0 };
+		double t, u, v, sl;
+		float c;
+		int w = rs::optimal_word(p, g, d.rmin, d.reverseCost, d.forwardCost, d.switchCost, t, u, v, c, sl);
+		// GetOptimalPath returns an empty PathSegment when no word is valid; its ComputeCost is +inf
+		table[idx] = w < 0 ? (double)__builtin_huge_valf() : (double)c;
+	}
+}
+
+// --------------------------------------------------------------------- knn --
+// One query per thread; points streamed through LDS tiles shared by the block.
+// Squared L2 in double, ascending; ties keep the lower point index.
+constexpr int kKnnMaxK = 16;
+constexpr int kKnnTile = 1024;
+__global__ void __launch_bounds__(kBlock) k_knn(int64_t nPoints, const double* __restrict__ pts, int64_t nQueries, const double* __restrict__ q, int k,
+	int32_t* __restrict__ idxOut, double* __restrict__ d2Out)
+{
+	__shared__ double2 tile[kKnnTile];
+	const int64_t qi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	double qx = 0, qy = 0;
+	if (qi < nQueries) {
+		qx = q[2 * qi];
+		qy = q[2 * qi + 1];
+	}
+	double bd[kKnnMaxK];
+	int bi[kKnnMaxK];
+#pragma unroll
+	for (int s = 0; s < kKnnMaxK; s++) {
+		bd[s] = __builtin_huge_val();
+		bi[s] = -1;
+	}
+	for (int64_t base = 0; base < nPoints; base += kKnnTile) {
+		const int cnt = (int)min((int64_t)kKnnTile, nPoints - base);
+		for (int i = threadIdx.x; i < cnt; i += kBlock)
+			tile[i] = reinterpret_cast<const double2*>(pts)[base + i];
+		__syncthreads();
+		if (qi < nQueries) {
+			for (int i = 0; i < cnt; i++) {
+				const double dx = tile[i].x - qx, dy = tile[i].y - qy;
+				const double d = dx * dx + dy * dy;
+				if (d < bd[k - 1]) {
+					// insert keeping ascending order; equal distances stay behind earlier indices
+					double cd = d;
+					int ci = (int)(base + i);
+					bool inserted = false;
+#pragma unroll
+					for (int s = 0; s < kKnnMaxK; s++) {
+						if (s < k && (inserted || cd < bd[s])) {
+							double td = bd[s];
+							int ti = bi[s];
+							bd[s] = cd;
+							bi[s] = ci;
+							cd = td;
+							ci = ti;
+							inserted = true;
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+	}
+	if (qi < nQueries) {
+		for (int s = 0; s < k; s++) {
+			idxOut[qi * k + s] = bi[s];
+			d2Out[qi * k + s] = bd[s];
+		}
+	}
+}
+
+} // namespace
+
+namespace pph {
+
+hipError_t launch_d2_to_distance(hipStream_t s, const int32_t* d2, float* dist, int64_t n, float res)
+{
+	hipLaunchKernelGGL(k_d2_to_distance, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, d2, dist, n, res);
+	return hipGetLastError();
+}
+hipError_t launch_occ_to_u8(hipStream_t s, const int32_t* occ, uint8_t* occ8, int64_t n)
+{
+	hipLaunchKernelGGL(k_occ_to_u8, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, occ, occ8, n);
+	return hipGetLastError();
+}
+hipError_t launch_check_states(hipStream_t s, const MapView& m, int64_t n, const double* poses, uint8_t* valid)
+{
+	if (n <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_check_states, dim3(grid_for(n, kBlock, 256 * 32)), dim3(kBlock), 0, s, m, n, poses, valid, (int)((((uintptr_t)poses) & 15) == 0));
+	return hipGetLastError();
+}
+hipError_t launch_check_states_fused(hipStream_t s, const MapView& m, int64_t n, uint64_t seed, uint64_t* count)
+{
+	hipError_t e = hipMemsetAsync(count, 0, sizeof(uint64_t), s);
+	if (e != hipSuccess)
+		return e;
+	if (n <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_check_states_fused, dim3(grid_for(n, kBlock, 256 * 8)), dim3(kBlock), 0, s, m, n, seed, (unsigned long long*)count);
+	return hipGetLastError();
+}
+hipError_t launch_check_arcs(hipStream_t s, const MapView& m, int64_t n, const double* from, const double* kappa, const double* length, const int32_t* dir,
+	uint8_t* valid, float* last)
+{
+	if (n <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_check_arcs, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, m, n, from, kappa, length, dir, valid, last);
+	return hipGetLastError();
+}
+hipError_t launch_check_segments(hipStream_t s, const MapView& m, int64_t n, const double* from, const double* to, uint8_t* valid)
+{
+	if (n <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_check_segments, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, m, n, from, to, valid);
+	return hipGetLastError();
+}
+hipError_t launch_rollout(hipStream_t s, const MapView& m, const RolloutParams& rp, const PrimTable& prims, int64_t nParents, const double* parents,
+	uint8_t* valid, double* pose, int32_t* key, double* cost, double* length)
+{
+	if (nParents <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_rollout, dim3(grid_for(nParents * prims.n, kBlock)), dim3(kBlock), 0, s, m, rp, prims, nParents, parents, valid, pose, key, cost, length);
+	return hipGetLastError();
+}
+hipError_t launch_rs_solve(hipStream_t s, int64_t n, const double* from, const double* to, double rmin, float rev, float fwd, float sw, int32_t* word, double* tuv,
+	float* cost, double* segLength)
+{
+	if (n <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_rs_solve, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, from, to, rmin, rev, fwd, sw, word, tuv, cost, segLength);
+	return hipGetLastError();
+}
+hipError_t launch_nonholo_build(hipStream_t s, const NonHoloDesc& d, double* table)
+{
+	const int64_t total = (int64_t)d.nx * d.ny * d.na;
+	hipLaunchKernelGGL(k_nonholo_build, dim3(grid_for(total, kBlock)), dim3(kBlock), 0, s, d, table);
+	return hipGetLastError();
+}
+hipError_t launch_knn(hipStream_t s, int64_t nPoints, const double* pts, int64_t nQueries, const double* q, int k, int32_t* idx, double* d2)
+{
+	if (nQueries <= 0)
+		return hipSuccess;
+	if (k < 1 || k > kKnnMaxK)
+		return hipErrorInvalidValue;
+	int64_t blocks = (nQueries + kBlock - 1) / kBlock;
+	hipLaunchKernelGGL(k_knn, dim3((unsigned)blocks), dim3(kBlock), 0, s, nPoints, pts, nQueries, q, k, idx, d2);
+	return hipGetLastError();
+}
+
+} // namespace pph

@@ -1,0 +1,912 @@
+// hybrid_astar_batch -- HybridAStar::SearchPath graph search (algo/hybrid_a_star.cpp:237-257,
+// 59-173; algo/a_star.h:326-427; utils/frontier.h) for a batch of independent queries.
+//
+// One wave (64 lanes) per query, all per-query state in HBM:
+//   lanes      = motion primitives of the node being expanded (rollout + IsPathValid +
+//                Voronoi cost + heuristic per child), then the 48 Reeds-Shepp words of the
+//                analytic expansion;
+//   open list  = 64-ary heap, pop is one coalesced 1 KiB load + wave arg-min per level;
+//   membership = dense key map over (x cell, y cell, heading bin): unseen / in the open list
+//                (node index) / explored -- replaces Frontier::Find + the explored hash set;
+//   RNG        = the query's own mt19937_64 (utils/random.h), twist done by the wave.
+// Results are bit-identical to the sequential reference as long as libm and OCML agree on
+// the discrete outcomes (cells, validity); continuous poses agree to ~1e-15.
+#include "pp_search_device.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+using namespace ppd;
+
+namespace {
+
+struct Node { // 64 bytes
+	double x, y, t;
+	double pathCost, totalCost;
+	double length;   // arc length after truncation / RS path length
+	int32_t parent;
+	uint32_t key;    // packed discrete pose
+	int16_t action;  // -1 root, 0..P-1 constant-steer primitive, 1000 + word for Reeds-Shepp
+	uint8_t dead;    // removed from the open list by ProcessPossibleShortcut
+	uint8_t pad[5];
+};
+static_assert(sizeof(Node) == 64, "Node layout");
+
+struct RsLogEntry {
+	int32_t node, word;
+	double t, u, v;
+};
+constexpr int kRsLogCap = 64;
+
+struct KeySpace {
+	int x0, y0, t0; // smallest representable discrete coordinate
+	int nx, ny, nt;
+	PPD_INLINE bool pack(int ix, int iy, int it, uint32_t& key) const
+	{
+		const int kx = ix - x0, ky = iy - y0, kt = it - t0;
+		if (kx < 0 || kx >= nx || ky < 0 || ky >= ny || kt < 0 || kt >= nt)
+			return false;
+		key = (uint32_t)((kx * ny + ky) * nt + kt);
+		return true;
+	}
+	__host__ __device__ void unpack(uint32_t key, int& ix, int& iy, int& it) const
+	{
+		it = (int)(key % (uint32_t)nt) + t0;
+		const uint32_t r = key / (uint32_t)nt;
+		iy = (int)(r % (uint32_t)ny) + y0;
+		ix = (int)(r / (uint32_t)ny) + x0;
+	}
+	__host__ __device__ size_t size() const { return (size_t)nx * ny * nt; }
+};
+
+struct SearchArgs {
+	MapView m;
+	pph::RolloutParams rp;
+	pph::PrimTable prims;
+	HeurView heur;
+	KeySpace ks;
+	double rmin;
+	float rsRev, rsFwd, rsSw; // Reeds-Shepp cost weights as floats (reeds_shepp.cpp:654)
+	int maxNodes;
+	size_t cells;
+};
+
+struct DevResult {
+	pp_query_result r;
+	int32_t solutionNode;
+	int32_t nRsLog;
+};
+
+constexpr uint32_t kExplored = 0xFFFFFFFFu;
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+
+__global__ void k_goal_cells(MapView m, int n, const double* __restrict__ goals, int32_t* __restrict__ cells)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	int row, col;
+	world_to_cell(m, goals[3 * i], goals[3 * i + 1], row, col);
+	cells[i] = inside_map(m, row, col) ? row * m.cols + col : -1; // WorldPositionToGridCell(bounded), heuristics.cpp:115
+}
+
+__global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries, const double* __restrict__ starts, const double* __restrict__ goals,
+	const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase, HeapEntry* __restrict__ heapBase,
+	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, DevResult* __restrict__ results)
+{
+	const int q = blockIdx.x;
+	if (q >= nQueries)
+		return;
+	const int lane = threadIdx.x;
+
+	__shared__ unsigned long long mt[Mt64::N];
+	// per-child staging (one slot per lane)
+	__shared__ double c_x[64], c_y[64], c_t[64], c_cost[64], c_total[64], c_len[64];
+	__shared__ uint32_t c_key[64], c_state[64];
+	__shared__ uint8_t c_valid[64], c_dup[64];
+	__shared__ int32_t c_node[64];
+	__shared__ int s_heapSize, s_nNodes, s_status;
+	__shared__ unsigned int s_seq;
+
+	const MapView& m = A.m;
+	const int P = A.prims.n;
+	const int maxNodes = A.maxNodes;
+	Node* nodes = nodesBase + (size_t)q * maxNodes;
+	HeapEntry* heap = heapBase + (size_t)q * maxNodes;
+	uint32_t* keymap = keymapBase + (size_t)q * A.ks.size();
+	uint32_t* expanded = expandedBase + (size_t)q * maxNodes;
+	RsLogEntry* rsLog = rsLogBase + (size_t)q * kRsLogCap;
+	const float* field = costFields + (size_t)q * A.cells;
+
+	// goal / start poses go through the Pose2d constructor on the caller's side (theta wrapped)
+	const Pose start = { starts[3 * q], starts[3 * q + 1], wrap_theta(starts[3 * q + 2]) };
+	const Pose goal = { goals[3 * q], goals[3 * q + 1], wrap_theta(goals[3 * q + 2]) };
+
+	// ---- InitializeSearch, a_star.h:350-364
+	{
+		const size_t n = A.ks.size();
+		const size_t n4 = n / 4; // keymap base is 16-byte aligned when n % 4 == 0; otherwise scalar
+		if ((((uintptr_t)keymap) & 15) == 0) {
+			uint4 z = { 0, 0, 0, 0 };
+			for (size_t i = lane; i < n4; i += 64)
+				reinterpret_cast<uint4*>(keymap)[i] = z;
+			for (size_t i = n4 * 4 + lane; i < n; i += 64)
+				keymap[i] = 0;
+		} else {
+			for (size_t i = lane; i < n; i += 64)
+				keymap[i] = 0;
+		}
+	}
+	if (lane == 0) {
+		Mt64::seed(mt, seeds[q]);
+		int ix, iy, it;
+		discretize_pose(start, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+		uint32_t key = kNoKey;
+		const bool ok = A.ks.pack(ix, iy, it, key);
+		Node root;
+		root.x = start.x;
+		root.y = start.y;
+		root.t = start.t;
+		root.pathCost = 0.0;
+		root.totalCost = 0.0;
+		root.length = 0.0;
+		root.parent = -1;
+		root.key = ok ? key : kNoKey;
+		root.action = -1;
+		root.dead = 0;
+		nodes[0] = root;
+		HeapEntry e;
+		e.ckey = cost_key(0.0);
+		e.nseq = 0xFFFFFFFFu;
+		e.node = 0;
+		heap[0] = e;
+		if (ok)
+			keymap[key] = kExplored; // the root is inserted in the explored set at init (a_star.h:361)
+		s_heapSize = 1;
+		s_nNodes = 1;
+		s_seq = 1;
+		s_status = 1; // 1 = running
+	}
+	int mtIdx = Mt64::N; // engine freshly seeded: first draw twists
+	__syncthreads();
+
+	int heapSize = 1, nNodes = 1;
+	int nExpanded = 0, nRngDraws = 0, nRsAttempts = 0, nRsLog = 0;
+	long long laneStateChecks = 0, lanePathChecks = 0; // this lane's arcs
+	long long rsStateChecks = 0, rsPathChecks = 0;     // wave-uniform (Reeds-Shepp children)
+	int status = -1, solutionNode = -1;
+	double solutionCost = __builtin_huge_val();
+
+	// ---- SearchPath main loop, a_star.h:337-345
+	while (heapSize > 0) {
+		const HeapEntry top = heap_pop_wave(heap, heapSize, lane);
+		if (lane == 0)
+			s_heapSize = heapSize;
+		__syncthreads();
+		const int ni = (int)top.node;
+		const Node parent = nodes[ni];
+		if (parent.dead)
+			continue; // entry of a node replaced by ProcessPossibleShortcut
+		const Pose ppose = { parent.x, parent.y, parent.t };
+		if (identical_poses(ppose, goal)) { // IsSolution, hybrid_a_star.h:193-196
+			status = 0;
+			solutionNode = ni;
+			solutionCost = parent.pathCost;
+			break;
+		}
+		// ---- Expand, a_star.h:377-409
+		if (lane == 0) {
+			if (parent.key != kNoKey)
+				keymap[parent.key] = kExplored;
+			expanded[nExpanded] = (uint32_t)ni;
+		}
+		__syncthreads(); // children landing in the parent's own cell must read it as explored
+		nExpanded++;
+		int pix, piy, pit;
+		discretize_pose(ppose, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, pix, piy, pit);
+
+		// RS gate input: heuristic of the node being expanded (hybrid_a_star.cpp:81)
+		const double hCost = combined_heuristic(A.heur, m, field, goal, ppose);
+
+		bool capacity = false;
+		// ---- constant-steer children, reference order p = 2*deltaIndex + direction (hybrid_a_star.cpp:65-77)
+		for (int base = 0; base < P; base += 64) {
+			const int p = base + lane;
+			bool ok = false;
+			uint32_t key = kNoKey;
+			Pose child = ppose;
+			double cost = 0.0, total = 0.0, len = 0.0;
+			if (p < P) {
+				Arc a;
+				a.init = ppose;
+				a.kappa = A.prims.kappa[p];
+				a.length = A.rp.arcLength;
+				a.backward = A.prims.backward[p];
+				child = a.interpolate(1.0);
+				int ix, iy, it;
+				discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+				float lastValidRatio;
+				int checks = 0;
+				ok = true;
+				lanePathChecks++;
+				if (!is_path_valid(m, a, a.init, lastValidRatio, checks)) {
+					child = a.interpolate((double)lastValidRatio);
+					a.length *= (double)lastValidRatio;
+					discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+					if (ix == pix && iy == piy && it == pit)
+						ok = false;
+				}
+				laneStateChecks += checks;
+				if (ok) {
+					const double pathCost = (a.backward ? A.rp.reverseMult : A.rp.forwardMult) * a.length;
+					const double voro = voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
+					cost = pathCost + 0.0 + voro; // switching cost is always 0 (hybrid_a_star.cpp:142)
+					len = a.length;
+					const double childPathCost = parent.pathCost + cost;
+					total = childPathCost + combined_heuristic(A.heur, m, field, goal, child); // a_star.h:387-388
+					cost = childPathCost;
+					if (!A.ks.pack(ix, iy, it, key))
+						ok = false; // outside the key map (cannot happen for poses inside the bounds)
+				}
+			}
+			c_valid[lane] = ok ? 1 : 0;
+			c_key[lane] = key;
+			c_x[lane] = child.x;
+			c_y[lane] = child.y;
+			c_t[lane] = child.t;
+			c_cost[lane] = cost;
+			c_total[lane] = total;
+			c_len[lane] = len;
+			c_state[lane] = ok ? keymap[key] : 0u;
+			c_node[lane] = -1;
+			__syncthreads();
+			// does an EARLIER valid child of this batch share my cell?  (then my prefetched state may be stale)
+			{
+				bool dup = false;
+				if (ok)
+					for (int e = 0; e < lane; e++)
+						if (c_valid[e] && c_key[e] == key)
+							dup = true;
+				c_dup[lane] = dup ? 1 : 0;
+			}
+			__syncthreads();
+			// ---- sequential insertion in child order (lane 0): a_star.h:391-402 + hybrid_a_star.h:199-205
+			if (lane == 0) {
+				int hs = s_heapSize, nn = s_nNodes;
+				unsigned int seq = s_seq;
+				const int cnt = min(64, P - base);
+				for (int c = 0; c < cnt; c++) {
+					if (!c_valid[c])
+						continue;
+					const uint32_t ckey = c_key[c];
+					const uint32_t st = c_dup[c] ? keymap[ckey] : c_state[c];
+					bool push = false;
+					if (st == 0u) {
+						push = true; // !inFrontier && !inExplored
+					} else if (st != kExplored) {
+						// in the open list: replace only if the poses are identical and the new path is strictly cheaper
+						const Node fn = nodes[st - 1];
+						const Pose fp = { fn.x, fn.y, fn.t };
+						const Pose cp = { c_x[c], c_y[c], c_t[c] };
+						if (identical_poses(fp, cp) && fn.totalCost > c_total[c]) {
+							nodes[st - 1].dead = 1;
+							push = true;
+						}
+					}
+					if (push) {
+						if (nn >= maxNodes) {
+							s_status = -4;
+							break;
+						}
+						const int idx = nn++;
+						c_node[c] = idx;
+						keymap[ckey] = (uint32_t)idx + 1u;
+						HeapEntry e;
+						e.ckey = cost_key(c_total[c]);
+						e.nseq = 0xFFFFFFFFu - seq;
+						seq++;
+						e.node = (uint32_t)idx;
+						heap_push(heap, hs, e);
+					}
+				}
+				s_heapSize = hs;
+				s_nNodes = nn;
+				s_seq = seq;
+			}
+			__syncthreads();
+			// ---- every lane writes the node record of its own child
+			if (c_node[lane] >= 0) {
+				Node nd;
+				nd.x = c_x[lane];
+				nd.y = c_y[lane];
+				nd.t = c_t[lane];
+				nd.pathCost = c_cost[lane];
+				nd.totalCost = c_total[lane];
+				nd.length = c_len[lane];
+				nd.parent = ni;
+				nd.key = c_key[lane];
+				nd.action = (int16_t)(base + lane);
+				nd.dead = 0;
+				nodes[c_node[lane]] = nd;
+			}
+			__syncthreads();
+			if (s_status == -4) {
+				capacity = true;
+				break;
+			}
+		}
+		if (capacity) {
+			status = -4;
+			break;
+		}
+
+		// ---- Reeds-Shepp analytic expansion, gated (hybrid_a_star.cpp:81-88): the RNG is drawn
+		// only when hCost >= 10 (short-circuit ||)
+		bool tryRs = hCost < 10.0;
+		if (!tryRs) {
+			if (mtIdx >= Mt64::N) {
+				Mt64::twist_wave(mt, lane);
+				mtIdx = 0;
+			}
+			const double u = Mt64::uniform01(Mt64::temper(mt[mtIdx]));
+			mtIdx++;
+			nRngDraws++;
+			tryRs = u < 10.0 / (hCost * hCost);
+		}
+		if (tryRs) {
+			nRsAttempts++;
+			// GetOptimalPath (reeds_shepp.cpp:654-683): lane w evaluates word w
+			Pose rel = rs::between(goal, ppose);
+			rel.x = rel.x / A.rmin;
+			rel.y = rel.y / A.rmin;
+			float wcost = __builtin_huge_valf();
+			double wt = 0, wu = 0, wv = 0;
+			bool wvalid = false;
+			if (lane < rs::kNumWords) {
+				double gx, gy, gt;
+				rs::goal_variant(rel, lane % 4, gx, gy, gt);
+				const double length = rs::base_lengths(lane / 4, gx, gy, gt, wt, wu, wv);
+				if (!(length == rs::inf())) {
+					rs::Segment sg;
+					rs::word_segment(lane, wt, wu, wv, sg);
+					wcost = rs::compute_cost(sg, A.rmin, A.rsRev, A.rsFwd, A.rsSw);
+					wvalid = wcost < __builtin_huge_valf(); // NaN and +inf never win a `cost < optimalCost` test
+				}
+			}
+			// first strictly-lowest float cost in word order
+			float best = wvalid ? wcost : __builtin_huge_valf();
+#pragma unroll
+			for (int off = 32; off > 0; off >>= 1)
+				best = fminf(best, __shfl_xor(best, off, 64));
+			const unsigned long long match = __ballot(wvalid && wcost == best);
+			const int word = match ? (__ffsll((long long)match) - 1) : -1;
+			if (word >= 0) {
+				const double bt = __shfl(wt, word, 64), bu = __shfl(wu, word, 64), bv = __shfl(wv, word, 64);
+				// the winner's path is validated by one lane (the adaptive march is sequential)
+				if (lane == 0) {
+					rs::Path path;
+					path.init = ppose;
+					rs::word_segment(word, bt, bu, bv, path.seg);
+					path.rmin = A.rmin;
+					path.length = path.seg.length * A.rmin; // PathSegment::GetLength
+					float lastRatio;
+					int checks = 0;
+					const bool valid = is_path_valid(m, path, path.init, lastRatio, checks);
+					c_valid[0] = 0;
+					c_state[0] = (uint32_t)checks;
+					if (valid) {
+						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
+						const Pose child = path.interpolate(1.0);
+						int ix, iy, it;
+						discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+						const double voro = voronoi_cost(m, path, A.rp.voroDiagRes, A.rp.voronoiMult);
+						const double cost = pathAndSwitchingCosts + voro;
+						uint32_t key;
+						if (A.ks.pack(ix, iy, it, key)) {
+							const double childPathCost = parent.pathCost + cost;
+							const double total = childPathCost + combined_heuristic(A.heur, m, field, goal, child);
+							const uint32_t st = keymap[key];
+							bool push = false;
+							if (st == 0u)
+								push = true;
+							else if (st != kExplored) {
+								const Node fn = nodes[st - 1];
+								const Pose fp = { fn.x, fn.y, fn.t };
+								if (identical_poses(fp, child) && fn.totalCost > total) {
+									nodes[st - 1].dead = 1;
+									push = true;
+								}
+							}
+							if (push) {
+								int hs = s_heapSize, nn = s_nNodes;
+								if (nn >= maxNodes) {
+									s_status = -4;
+								} else {
+									const int idx = nn++;
+									Node nd;
+									nd.x = child.x;
+									nd.y = child.y;
+									nd.t = child.t;
+									nd.pathCost = childPathCost;
+									nd.totalCost = total;
+									nd.length = path.length;
+									nd.parent = ni;
+									nd.key = key;
+									nd.action = (int16_t)(1000 + word);
+									nd.dead = 0;
+									nodes[idx] = nd;
+									keymap[key] = (uint32_t)idx + 1u;
+									HeapEntry e;
+									e.ckey = cost_key(total);
+									e.nseq = 0xFFFFFFFFu - s_seq;
+									s_seq = s_seq + 1;
+									e.node = (uint32_t)idx;
+									heap_push(heap, hs, e);
+									s_heapSize = hs;
+									s_nNodes = nn;
+									c_valid[0] = 1;
+									c_node[0] = idx;
+								}
+							}
+						}
+					}
+				}
+				__syncthreads();
+				rsPathChecks++;
+				rsStateChecks += (long long)c_state[0];
+				if (c_valid[0]) {
+					if (lane == 0 && nRsLog < kRsLogCap) {
+						RsLogEntry le;
+						le.node = c_node[0];
+						le.word = word;
+						le.t = bt;
+						le.u = bu;
+						le.v = bv;
+						rsLog[nRsLog] = le;
+					}
+					nRsLog++;
+				}
+				__syncthreads();
+				if (s_status == -4) {
+					status = -4;
+					break;
+				}
+			}
+		}
+		heapSize = s_heapSize;
+		nNodes = s_nNodes;
+		__syncthreads();
+	}
+
+	// lane-local counters -> totals
+	for (int off = 32; off > 0; off >>= 1) {
+		laneStateChecks += __shfl_xor(laneStateChecks, off, 64);
+		lanePathChecks += __shfl_xor(lanePathChecks, off, 64);
+	}
+	const long long nStateChecks = laneStateChecks + rsStateChecks;
+	const long long pathChecks = lanePathChecks + rsPathChecks;
+	if (lane == 0) {
+		DevResult r;
+		r.r.status = status;
+		r.r.n_expanded = nExpanded;
+		r.r.n_nodes = s_nNodes;
+		r.r.n_path = 0;
+		if (status == 0) {
+			int depth = 0;
+			for (int k = solutionNode; k >= 0; k = nodes[k].parent)
+				depth++;
+			r.r.n_path = depth;
+		}
+		r.r.cost = solutionCost;
+		r.r.n_rng_draws = nRngDraws;
+		r.r.n_rs_attempts = nRsAttempts;
+		r.r.n_state_checks = nStateChecks;
+		r.r.n_path_checks = pathChecks;
+		r.solutionNode = solutionNode;
+		r.nRsLog = nRsLog < kRsLogCap ? nRsLog : kRsLogCap;
+		results[q] = r;
+	}
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+struct pp_planner {
+	pp_map* map = nullptr;
+	pp_hybrid_params params {};
+	int maxBatch = 0, maxNodes = 0;
+	SearchArgs args {};
+	pph::NonHoloDesc nh {};
+	std::vector<double> deltas;
+	// device
+	double* table = nullptr;
+	bool tableReady = false;
+	float* costFields = nullptr;
+	void* wfWorkspace = nullptr;
+	int64_t wfBytesPerSlot = 0;
+	int wfSlots = 0;
+	int32_t* wfError = nullptr;
+	int32_t* goalCells = nullptr;
+	Node* nodes = nullptr;
+	HeapEntry* heaps = nullptr;
+	uint32_t* keymaps = nullptr;
+	uint32_t* expanded = nullptr;
+	RsLogEntry* rsLogs = nullptr;
+	DevResult* results = nullptr;
+	double *dStarts = nullptr, *dGoals = nullptr;
+	uint64_t* dSeeds = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+	float wavefrontMs = 0, searchMs = 0;
+	int lastBatch = 0;
+	std::vector<DevResult> hostResults;
+};
+
+namespace {
+
+using pph::set_error;
+
+void free_planner(pp_planner* p)
+{
+	if (!p)
+		return;
+	void* ptrs[] = { p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->dStarts,
+		p->dGoals, p->dSeeds };
+	for (void* q : ptrs)
+		if (q)
+			(void)hipFree(q);
+	if (p->e0)
+		(void)hipEventDestroy(p->e0);
+	if (p->e1)
+		(void)hipEventDestroy(p->e1);
+	if (p->e2)
+		(void)hipEventDestroy(p->e2);
+	delete p;
+}
+
+} // namespace
+
+extern "C" {
+
+int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, pp_planner** out)
+{
+	if (!map || !params || !out || max_batch < 1 || max_nodes_per_query < 16) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	if (!map->dist || !map->occ8 || !map->pathcost) {
+		set_error("map set incomplete: upload dist2, occupancy and path cost first");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(map->ctx->device));
+	auto* p = new pp_planner();
+	p->map = map;
+	p->params = *params;
+	p->maxBatch = max_batch;
+	p->maxNodes = max_nodes_per_query;
+
+	// StatePropagator constructor, hybrid_a_star.cpp:13-29: deltas {0, +d1, -d1, +d2, -d2, ...}
+	const double wheelbase = params->wheelbase, rearToCenter = 0.0;
+	// GetSteeringAngleFromTurningRadius, kinematic_bicycle_model.cpp:34-41
+	const double deltaMax = std::atan(wheelbase / std::sqrt(std::pow(params->min_turning_radius, 2) - std::pow(rearToCenter, 2)));
+	p->deltas.push_back(0.0);
+	for (unsigned int i = 0; i < params->num_generated_motion / 2; i++) {
+		double delta = (i + 1) / 2.0 * deltaMax;
+		p->deltas.push_back(delta);
+		p->deltas.push_back(-delta);
+	}
+	const int P = 2 * (int)p->deltas.size();
+	if (P > pph::kMaxPrimitives) {
+		set_error("too many motion primitives");
+		free_planner(p);
+		return PP_ERR_INVALID;
+	}
+	SearchArgs& A = p->args;
+	A.m = map->view();
+	A.prims.n = P;
+	for (size_t d = 0; d < p->deltas.size(); d++) {
+		// ConstantSteer, kinematic_bicycle_model.cpp:13-17 with rearToCenter = 0
+		const double tanSteering = std::tan(p->deltas[d]);
+		const double beta = std::atan(rearToCenter * tanSteering / wheelbase);
+		const double cosBeta = std::cos(beta);
+		const double DthetaDdist = cosBeta * tanSteering / wheelbase;
+		A.prims.kappa[2 * d] = DthetaDdist;
+		A.prims.backward[2 * d] = 0;
+		A.prims.kappa[2 * d + 1] = DthetaDdist;
+		A.prims.backward[2 * d + 1] = 1;
+	}
+	A.rp.arcLength = params->spatial_resolution * 1.5;
+	A.rp.spatialRes = params->spatial_resolution;
+	A.rp.angularRes = params->angular_resolution;
+	A.rp.forwardMult = params->forward_cost_multiplier;
+	A.rp.reverseMult = params->reverse_cost_multiplier;
+	A.rp.voronoiMult = params->voronoi_cost_multiplier;
+	A.rp.voroDiagRes = (float)(map->desc.resolution * std::sqrt(2.0));
+	A.rp.headingAlias = params->heading_alias;
+	int32_t dims[3];
+	double offs[2];
+	if (int rc = pp_nonholo_dims(map->desc.lower, map->desc.upper, params, dims, offs)) {
+		free_planner(p);
+		return rc;
+	}
+	A.heur.nx = dims[0];
+	A.heur.ny = dims[1];
+	A.heur.na = dims[2];
+	A.heur.spatialRes = params->spatial_resolution;
+	A.heur.angularRes = params->angular_resolution;
+	A.heur.offX = offs[0];
+	A.heur.offY = offs[1];
+	A.heur.minMult = std::min(params->reverse_cost_multiplier, params->forward_cost_multiplier);
+	A.heur.negativeKRead = params->negative_k_read;
+	// ObstaclesHeuristic constructor, heuristics.cpp:97-104
+	A.heur.obstDiagRes = (float)(std::sqrt(2) * map->desc.resolution);
+	A.heur.obstCostMult = (float)(std::min(params->reverse_cost_multiplier, params->forward_cost_multiplier) * map->desc.resolution);
+	A.rmin = params->min_turning_radius;
+	A.rsRev = (float)params->reverse_cost_multiplier;
+	A.rsFwd = (float)params->forward_cost_multiplier;
+	A.rsSw = (float)params->direction_switching_cost;
+	A.maxNodes = max_nodes_per_query;
+	A.cells = map->cells();
+	// key space: every discrete pose a state inside the bounds (plus one arc of slack) can take
+	{
+		const double sres = params->spatial_resolution, ares = params->angular_resolution;
+		const double slack = A.rp.arcLength + 1.0;
+		KeySpace& ks = A.ks;
+		ks.x0 = (int)std::floor((map->desc.lower[0] - slack) / sres) - 1;
+		ks.y0 = (int)std::floor((map->desc.lower[1] - slack) / sres) - 1;
+		ks.nx = (int)std::ceil((map->desc.upper[0] + slack) / sres) + 1 - ks.x0 + 1;
+		ks.ny = (int)std::ceil((map->desc.upper[1] + slack) / sres) + 1 - ks.y0 + 1;
+		const int tmax = (int)(M_PI / ares) + 1;
+		ks.t0 = -tmax;
+		ks.nt = 2 * tmax + 1;
+		ks.nt = (ks.nt + 3) / 4 * 4; // keeps every query's key map 16-byte aligned
+	}
+
+	const size_t B = (size_t)max_batch, N = (size_t)max_nodes_per_query;
+	const size_t tableBytes = (size_t)dims[0] * dims[1] * dims[2] * sizeof(double);
+	p->wfBytesPerSlot = pph::wavefront_workspace_bytes(map->desc.rows, map->desc.cols);
+	p->wfSlots = max_batch < 768 ? max_batch : 768;
+	hipError_t e = hipSuccess;
+	auto alloc = [&](void** ptr, size_t bytes) {
+		if (e == hipSuccess)
+			e = hipMalloc(ptr, bytes ? bytes : 1);
+	};
+	alloc((void**)&p->table, tableBytes);
+	alloc((void**)&p->costFields, B * A.cells * sizeof(float));
+	alloc((void**)&p->wfWorkspace, (size_t)p->wfBytesPerSlot * p->wfSlots);
+	alloc((void**)&p->wfError, 4);
+	alloc((void**)&p->goalCells, B * 4);
+	alloc((void**)&p->nodes, B * N * sizeof(Node));
+	alloc((void**)&p->heaps, B * N * sizeof(HeapEntry));
+	alloc((void**)&p->keymaps, B * A.ks.size() * 4);
+	alloc((void**)&p->expanded, B * N * 4);
+	alloc((void**)&p->rsLogs, B * kRsLogCap * sizeof(RsLogEntry));
+	alloc((void**)&p->results, B * sizeof(DevResult));
+	alloc((void**)&p->dStarts, B * 24);
+	alloc((void**)&p->dGoals, B * 24);
+	alloc((void**)&p->dSeeds, B * 8);
+	if (e == hipSuccess)
+		e = hipEventCreate(&p->e0);
+	if (e == hipSuccess)
+		e = hipEventCreate(&p->e1);
+	if (e == hipSuccess)
+		e = hipEventCreate(&p->e2);
+	if (e != hipSuccess) {
+		free_planner(p);
+		return pph::hip_fail(e, "planner allocation");
+	}
+	A.heur.table = p->table;
+	p->nh.nx = dims[0];
+	*out = p;
+	return PP_OK;
+}
+
+int pp_planner_destroy(pp_planner* planner)
+{
+	if (!planner)
+		return PP_OK;
+	(void)hipSetDevice(planner->map->ctx->device);
+	(void)hipStreamSynchronize(planner->map->ctx->stream);
+	free_planner(planner);
+	return PP_OK;
+}
+
+int pp_planner_num_primitives(pp_planner* planner) { return planner ? planner->args.prims.n : 0; }
+
+int pp_planner_set_nonholo_table(pp_planner* planner, const double* table_host)
+{
+	if (!planner) {
+		set_error("null planner");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	hipStream_t s = planner->map->ctx->stream;
+	const HeurView& h = planner->args.heur;
+	const size_t bytes = (size_t)h.nx * h.ny * h.na * sizeof(double);
+	if (table_host) {
+		PP_HIP_TRY(hipMemcpyAsync(planner->table, table_host, bytes, hipMemcpyHostToDevice, s));
+	} else {
+		if (int rc = pp_nonholo_build_dev(planner->map->ctx, planner->map->desc.lower, planner->map->desc.upper, &planner->params, planner->table))
+			return rc;
+	}
+	PP_HIP_TRY(hipStreamSynchronize(s));
+	planner->tableReady = true;
+	return PP_OK;
+}
+
+int pp_planner_get_nonholo_table(pp_planner* planner, double* table_host)
+{
+	if (!planner || !table_host || !planner->tableReady) {
+		set_error("table not available");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	const HeurView& h = planner->args.heur;
+	PP_HIP_TRY(hipMemcpy(table_host, planner->table, (size_t)h.nx * h.ny * h.na * sizeof(double), hipMemcpyDeviceToHost));
+	return PP_OK;
+}
+
+int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const double* starts_dev, const double* goals_dev, const uint64_t* seeds_dev)
+{
+	if (!planner || n_queries < 0 || n_queries > planner->maxBatch || (n_queries > 0 && (!starts_dev || !goals_dev || !seeds_dev))) {
+		set_error("invalid arguments (n_queries must be <= max_batch)");
+		return PP_ERR_INVALID;
+	}
+	if (n_queries == 0)
+		return PP_OK;
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	if (!planner->tableReady)
+		if (int rc = pp_planner_set_nonholo_table(planner, nullptr))
+			return rc;
+	hipStream_t s = planner->map->ctx->stream;
+	planner->args.m = planner->map->view(); // validator tunables may have changed
+	const MapView& m = planner->args.m;
+	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 4, s));
+	PP_HIP_TRY(hipEventRecord(planner->e0, s));
+	hipLaunchKernelGGL(k_goal_cells, dim3((n_queries + 255) / 256), dim3(256), 0, s, m, n_queries, goals_dev, planner->goalCells);
+	PP_HIP_TRY(hipGetLastError());
+	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
+	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, planner->goalCells, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
+		planner->wfError));
+	PP_HIP_TRY(hipEventRecord(planner->e1, s));
+	hipLaunchKernelGGL(k_hybrid_search, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
+		planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->results);
+	PP_HIP_TRY(hipGetLastError());
+	PP_HIP_TRY(hipEventRecord(planner->e2, s));
+	planner->lastBatch = n_queries;
+	return PP_OK;
+}
+
+int pp_planner_fetch_results(pp_planner* planner, int32_t n_queries, pp_query_result* results_host)
+{
+	if (!planner || n_queries < 0 || n_queries > planner->lastBatch || (n_queries > 0 && !results_host)) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	hipStream_t s = planner->map->ctx->stream;
+	planner->hostResults.resize(planner->lastBatch);
+	int32_t err = 0;
+	PP_HIP_TRY(hipMemcpyAsync(planner->hostResults.data(), planner->results, (size_t)planner->lastBatch * sizeof(DevResult), hipMemcpyDeviceToHost, s));
+	PP_HIP_TRY(hipMemcpyAsync(&err, planner->wfError, 4, hipMemcpyDeviceToHost, s));
+	PP_HIP_TRY(hipStreamSynchronize(s));
+	(void)hipEventElapsedTime(&planner->wavefrontMs, planner->e0, planner->e1);
+	(void)hipEventElapsedTime(&planner->searchMs, planner->e1, planner->e2);
+	if (err) {
+		set_error("obstacle-heuristic open list exceeded its workspace");
+		return PP_ERR_CAPACITY;
+	}
+	for (int i = 0; i < n_queries; i++)
+		results_host[i] = planner->hostResults[i].r;
+	return PP_OK;
+}
+
+int pp_planner_search_batch(pp_planner* planner, int32_t n_queries, const double* starts_host, const double* goals_host, const uint64_t* seeds_host,
+	pp_query_result* results_host)
+{
+	if (!planner || n_queries < 0 || n_queries > planner->maxBatch || (n_queries > 0 && (!starts_host || !goals_host || !seeds_host || !results_host))) {
+		set_error("invalid arguments (n_queries must be <= max_batch)");
+		return PP_ERR_INVALID;
+	}
+	if (n_queries == 0)
+		return PP_OK;
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	hipStream_t s = planner->map->ctx->stream;
+	PP_HIP_TRY(hipMemcpyAsync(planner->dStarts, starts_host, (size_t)n_queries * 24, hipMemcpyHostToDevice, s));
+	PP_HIP_TRY(hipMemcpyAsync(planner->dGoals, goals_host, (size_t)n_queries * 24, hipMemcpyHostToDevice, s));
+	PP_HIP_TRY(hipMemcpyAsync(planner->dSeeds, seeds_host, (size_t)n_queries * 8, hipMemcpyHostToDevice, s));
+	if (int rc = pp_planner_search_batch_dev(planner, n_queries, planner->dStarts, planner->dGoals, planner->dSeeds))
+		return rc;
+	return pp_planner_fetch_results(planner, n_queries, results_host);
+}
+
+int pp_planner_last_timings(pp_planner* planner, float* wavefront_ms, float* search_ms)
+{
+	if (!planner) {
+		set_error("null planner");
+		return PP_ERR_INVALID;
+	}
+	if (wavefront_ms)
+		*wavefront_ms = planner->wavefrontMs;
+	if (search_ms)
+		*search_ms = planner->searchMs;
+	return PP_OK;
+}
+
+int pp_planner_get_path(pp_planner* planner, int32_t q, double* poses_host, int32_t* kind_host, int32_t* prim_host, double* length_host, double* tuv_host)
+{
+	if (!planner || q < 0 || q >= planner->lastBatch || (int)planner->hostResults.size() <= q) {
+		set_error("no fetched result for this query (call pp_planner_fetch_results first)");
+		return PP_ERR_INVALID;
+	}
+	const DevResult& r = planner->hostResults[q];
+	if (r.r.status != 0 || r.solutionNode < 0)
+		return PP_OK; // empty path
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	const int nNodes = r.r.n_nodes;
+	std::vector<Node> nodes(nNodes);
+	PP_HIP_TRY(hipMemcpy(nodes.data(), planner->nodes + (size_t)q * planner->maxNodes, (size_t)nNodes * sizeof(Node), hipMemcpyDeviceToHost));
+	std::vector<RsLogEntry> rslog(r.nRsLog);
+	if (r.nRsLog)
+		PP_HIP_TRY(hipMemcpy(rslog.data(), planner->rsLogs + (size_t)q * kRsLogCap, (size_t)r.nRsLog * sizeof(RsLogEntry), hipMemcpyDeviceToHost));
+	std::vector<int> chain;
+	for (int k = r.solutionNode; k >= 0; k = nodes[k].parent)
+		chain.push_back(k);
+	for (size_t i = 0; i < chain.size(); i++) {
+		const Node& n = nodes[chain[chain.size() - 1 - i]];
+		const int idx = chain[chain.size() - 1 - i];
+		if (poses_host) {
+			poses_host[3 * i] = n.x;
+			poses_host[3 * i + 1] = n.y;
+			poses_host[3 * i + 2] = n.t;
+		}
+		const int kind = n.action < 0 ? 0 : (n.action >= 1000 ? 2 : 1);
+		if (kind_host)
+			kind_host[i] = kind;
+		if (prim_host)
+			prim_host[i] = kind == 2 ? n.action - 1000 : n.action;
+		if (length_host)
+			length_host[i] = n.length;
+		if (tuv_host) {
+			tuv_host[3 * i] = tuv_host[3 * i + 1] = tuv_host[3 * i + 2] = 0.0;
+			if (kind == 2)
+				for (const auto& le : rslog)
+					if (le.node == idx) {
+						tuv_host[3 * i] = le.t;
+						tuv_host[3 * i + 1] = le.u;
+						tuv_host[3 * i + 2] = le.v;
+					}
+		}
+	}
+	return PP_OK;
+}
+
+int pp_planner_get_expanded(pp_planner* planner, int32_t q, int32_t* cells_host)
+{
+	if (!planner || q < 0 || q >= planner->lastBatch || (int)planner->hostResults.size() <= q || !cells_host) {
+		set_error("no fetched result for this query (call pp_planner_fetch_results first)");
+		return PP_ERR_INVALID;
+	}
+	const DevResult& r = planner->hostResults[q];
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	const int ne = r.r.n_expanded;
+	if (ne == 0)
+		return PP_OK;
+	std::vector<uint32_t> idx(ne);
+	PP_HIP_TRY(hipMemcpy(idx.data(), planner->expanded + (size_t)q * planner->maxNodes, (size_t)ne * 4, hipMemcpyDeviceToHost));
+	std::vector<Node> nodes(r.r.n_nodes);
+	PP_HIP_TRY(hipMemcpy(nodes.data(), planner->nodes + (size_t)q * planner->maxNodes, (size_t)r.r.n_nodes * sizeof(Node), hipMemcpyDeviceToHost));
+	const KeySpace& ks = planner->args.ks;
+	for (int i = 0; i < ne; i++) {
+		const Node& n = nodes[idx[i]];
+		int ix = 0, iy = 0, it = 0;
+		if (n.key != kNoKey)
+			ks.unpack(n.key, ix, iy, it);
+		cells_host[3 * i] = ix;
+		cells_host[3 * i + 1] = iy;
+		cells_host[3 * i + 2] = it;
+	}
+	return PP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,453 @@
+"""Host-side mirror of the reference's operator interface for the hot path, on top of the C ABI.
+
+Class / method names follow the reference's pybind11 module (interfaces/python/src/pyplanning.cpp)
+where a counterpart exists: StateValidatorOccupancyMap.is_state_valid / is_path_valid,
+HybridAStar.set_init_state / set_goal_state / search_path / get_path, Status.  Batched entry
+points are the MI355X-native addition.  Everything computes on the GPU through libpphip.so;
+nothing here falls back to the CPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import HybridParams, MapDesc, QueryResult, check, ptr
+
+
+class Status:
+    """algo/path_planner.h:9-12"""
+    SUCCESS = 0
+    FAILURE = -1
+
+
+def _f64(a, cols):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    return a.reshape(-1, cols)
+
+
+def _is_tensor(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+def _dev_ptr(t):
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One device + one HIP stream.  `stream` may be a raw hipStream_t (int), e.g.
+    torch.cuda.current_stream().cuda_stream, so that torch events see the work."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.pp_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def synchronize(self):
+        check(self.lib.pp_ctx_synchronize(self.h))
+
+    def timer_start(self):
+        check(self.lib.pp_ctx_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.lib.pp_ctx_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.pp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OccupancyMapSet:
+    """Device-resident data of one OccupancyMap + GVD: squared-distance grid, occupancy, Voronoi
+    potential, plus the StateSpaceSE2 bounds (state_validator/occupancy_map.h:122-133)."""
+
+    def __init__(self, ctx, lower, upper, resolution, rows, cols, grid_origin, local_origin=(0.0, 0.0)):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.lower = np.asarray(lower, dtype=np.float64)
+        self.upper = np.asarray(upper, dtype=np.float64)
+        self.resolution = np.float32(resolution)
+        self.rows, self.cols = int(rows), int(cols)
+        self.grid_origin = np.asarray(grid_origin, dtype=np.float64)
+        d = MapDesc()
+        d.rows, d.cols, d.resolution = self.rows, self.cols, float(self.resolution)
+        d.grid_origin[:] = list(self.grid_origin)
+        d.local_origin[:] = list(local_origin)
+        d.lower[:] = list(self.lower)
+        d.upper[:] = list(self.upper)
+        self.desc = d
+        h = C.c_void_p()
+        check(self.lib.pp_map_create(ctx.h, C.byref(d), C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_bounds(cls, ctx, lower, upper, resolution):
+        """Sizes the grid like StateValidatorOccupancyMap's constructor + OccupancyMap::InitializeSize
+        (state_validator_occupancy_map.cpp:6-13, occupancy_map.cpp:6-14): float width/height."""
+        lower = np.asarray(lower, dtype=np.float64)
+        upper = np.asarray(upper, dtype=np.float64)
+        res = np.float32(resolution)
+        width = np.float32(upper[0] - lower[0])
+        height = np.float32(upper[1] - lower[1])
+        origin = (-float(width) / 2.0, -float(height) / 2.0)
+        rows = int(math.ceil(float(np.float32(width / res))))
+        cols = int(math.ceil(float(np.float32(height / res))))
+        return cls(ctx, lower, upper, res, rows, cols, origin)
+
+    def upload_dist2(self, d2):
+        d2 = np.ascontiguousarray(d2, dtype=np.int32)
+        assert d2.shape == (self.rows, self.cols)
+        check(self.lib.pp_map_upload_dist2(self.h, ptr(d2)))
+
+    def upload_occupancy(self, occ):
+        occ = np.ascontiguousarray(occ, dtype=np.int32)
+        assert occ.shape == (self.rows, self.cols)
+        check(self.lib.pp_map_upload_occupancy(self.h, ptr(occ)))
+
+    def upload_path_cost(self, cost):
+        cost = np.ascontiguousarray(cost, dtype=np.float32)
+        assert cost.shape == (self.rows, self.cols)
+        check(self.lib.pp_map_upload_path_cost(self.h, ptr(cost)))
+
+    def download_distance(self):
+        out = np.empty((self.rows, self.cols), dtype=np.float32)
+        check(self.lib.pp_map_download_distance(self.h, ptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.pp_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StateValidatorOccupancyMap:
+    """state_validator/state_validator_occupancy_map.{h,cpp}: is_state_valid / is_path_valid, batched."""
+
+    def __init__(self, map_set):
+        self.map = map_set
+        self.lib = map_set.lib
+        self._min_safe_radius = 1.0
+        self._min_interp = 0.1
+        self._push()
+
+    def _push(self):
+        check(self.lib.pp_map_set_validator(self.map.h, C.c_float(self._min_safe_radius), C.c_float(self._min_interp)))
+
+    @property
+    def min_safe_radius(self):
+        return self._min_safe_radius
+
+    @min_safe_radius.setter
+    def min_safe_radius(self, v):
+        self._min_safe_radius = float(v)
+        self._push()
+
+    @property
+    def min_path_interpolation_distance(self):
+        return self._min_interp
+
+    @min_path_interpolation_distance.setter
+    def min_path_interpolation_distance(self, v):
+        self._min_interp = float(v)
+        self._push()
+
+    def get_occupancy_map(self):
+        return self.map
+
+    def is_state_valid(self, poses):
+        """poses: (n, 3) array-like -> bool array; or a CUDA float64 tensor -> CUDA uint8 tensor."""
+        if _is_tensor(poses):
+            import torch
+            n = poses.numel() // 3
+            out = torch.empty(n, dtype=torch.uint8, device=poses.device)
+            check(self.lib.pp_check_states_dev(self.map.h, n, _dev_ptr(poses), _dev_ptr(out)))
+            return out
+        p = _f64(poses, 3)
+        out = np.empty(len(p), dtype=np.uint8)
+        check(self.lib.pp_check_states(self.map.h, len(p), ptr(p), ptr(out)))
+        return out.astype(bool)
+
+    def is_path_valid(self, start, curvature, length, direction):
+        """IsPathValid over constant-steer arcs.  Returns (valid, last_valid_ratio)."""
+        s = _f64(start, 3)
+        n = len(s)
+        k = np.ascontiguousarray(np.broadcast_to(np.asarray(curvature, dtype=np.float64), n))
+        ln = np.ascontiguousarray(np.broadcast_to(np.asarray(length, dtype=np.float64), n))
+        d = np.ascontiguousarray(np.broadcast_to(np.asarray(direction, dtype=np.int32), n))
+        valid = np.empty(n, dtype=np.uint8)
+        last = np.empty(n, dtype=np.float32)
+        check(self.lib.pp_check_arcs(self.map.h, n, ptr(s), ptr(k), ptr(ln), ptr(d), ptr(valid), ptr(last)))
+        return valid.astype(bool), last
+
+    def is_segment_valid(self, start_xy, end_xy):
+        a = _f64(start_xy, 2)
+        b = _f64(end_xy, 2)
+        valid = np.empty(len(a), dtype=np.uint8)
+        check(self.lib.pp_check_segments(self.map.h, len(a), ptr(a), ptr(b), ptr(valid)))
+        return valid.astype(bool)
+
+    def count_valid_fused(self, n, seed, count_tensor):
+        check(self.lib.pp_check_states_fused_dev(self.map.h, int(n), C.c_uint64(seed), _dev_ptr(count_tensor)))
+
+
+class HybridAStarSearchParameters:
+    """HybridAStar::SearchParameters, algo/hybrid_a_star.h:29-50 (same 8-argument constructor order as
+    pyplanning.cpp:73-75) plus the two reference-behaviour switches."""
+
+    def __init__(self, min_turning_radius=2.0, direction_switching_cost=0.0, reverse_cost_multiplier=1.0, forward_cost_multiplier=1.0,
+                 voronoi_cost_multiplier=1.0, num_generated_motion=5, spatial_resolution=1.0, angular_resolution=0.0872, wheelbase=2.6,
+                 heading_alias=True, negative_k_read=True):
+        self.wheelbase = wheelbase
+        self.min_turning_radius = min_turning_radius
+        self.direction_switching_cost = direction_switching_cost
+        self.reverse_cost_multiplier = reverse_cost_multiplier
+        self.forward_cost_multiplier = forward_cost_multiplier
+        self.voronoi_cost_multiplier = voronoi_cost_multiplier
+        self.num_generated_motion = num_generated_motion
+        self.spatial_resolution = spatial_resolution
+        self.angular_resolution = angular_resolution
+        self.heading_alias = heading_alias
+        self.negative_k_read = negative_k_read
+
+    def to_c(self):
+        return HybridParams(self.wheelbase, self.min_turning_radius, self.direction_switching_cost, self.reverse_cost_multiplier,
+                            self.forward_cost_multiplier, self.voronoi_cost_multiplier, int(self.num_generated_motion), self.spatial_resolution,
+                            self.angular_resolution, int(bool(self.heading_alias)), int(bool(self.negative_k_read)))
+
+    def primitives(self):
+        """Steering angles / curvatures / directions in the reference's child order
+        (hybrid_a_star.cpp:21-28,65-77; kinematic_bicycle_model.cpp:13-17,34-41)."""
+        delta_max = math.atan(self.wheelbase / math.sqrt(math.pow(self.min_turning_radius, 2) - math.pow(0.0, 2)))
+        deltas = [0.0]
+        for i in range(int(self.num_generated_motion) // 2):
+            d = (i + 1) / 2.0 * delta_max
+            deltas += [d, -d]
+        curv, direc, steer = [], [], []
+        for d in deltas:
+            tan_s = math.tan(d)
+            beta = math.atan(0.0 * tan_s / self.wheelbase)
+            k = math.cos(beta) * tan_s / self.wheelbase
+            for dr in (0, 1):
+                curv.append(k)
+                direc.append(dr)
+                steer.append(d)
+        return np.array(steer), np.array(curv), np.array(direc, dtype=np.int32)
+
+
+class ReedsSheppSolver:
+    """ReedsShepp::Solver::GetOptimalPath, batched (geometry/reeds_shepp.cpp:654-683)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lib = ctx.lib
+
+    def get_optimal_path(self, start, goal, min_turning_radius, reverse_cost=1.0, forward_cost=1.0, switch_cost=0.0):
+        a, b = _f64(start, 3), _f64(goal, 3)
+        n = len(a)
+        word = np.empty(n, dtype=np.int32)
+        tuv = np.empty((n, 3))
+        cost = np.empty(n, dtype=np.float32)
+        seg = np.empty(n)
+        check(self.lib.pp_rs_solve(self.ctx.h, n, ptr(a), ptr(b), C.c_double(min_turning_radius), C.c_float(reverse_cost), C.c_float(forward_cost),
+                                   C.c_float(switch_cost), ptr(word), ptr(tuv), ptr(cost), ptr(seg)))
+        return word, tuv, cost, seg
+
+
+class NonHolonomicHeuristic:
+    """NonHolonomicHeuristic::Build (algo/heuristics.cpp:36-76) on the device."""
+
+    @staticmethod
+    def build(ctx, lower, upper, params):
+        lo = np.ascontiguousarray(lower, dtype=np.float64)
+        up = np.ascontiguousarray(upper, dtype=np.float64)
+        cp = params.to_c()
+        dims = np.zeros(3, dtype=np.int32)
+        offs = np.zeros(2)
+        check(ctx.lib.pp_nonholo_dims(ptr(lo), ptr(up), C.byref(cp), ptr(dims), ptr(offs)))
+        table = np.empty(tuple(int(x) for x in dims))
+        check(ctx.lib.pp_nonholo_build(ctx.h, ptr(lo), ptr(up), C.byref(cp), ptr(table)))
+        return table, offs
+
+
+class ObstaclesHeuristic:
+    """ObstaclesHeuristic::Update (algo/heuristics.cpp:106-153): one exact-order wavefront per goal."""
+
+    def __init__(self, map_set):
+        self.map = map_set
+        self.lib = map_set.lib
+
+    def update(self, goals_xy):
+        g = _f64(goals_xy, 2)
+        out = np.empty((len(g), self.map.rows, self.map.cols), dtype=np.float32)
+        check(self.lib.pp_obstacle_heuristic(self.map.h, len(g), ptr(g), ptr(out)))
+        return out
+
+    def update_dev(self, goals_xy, cost_tensor):
+        g = _f64(goals_xy, 2)
+        check(self.lib.pp_obstacle_heuristic_dev(self.map.h, len(g), ptr(g), _dev_ptr(cost_tensor)))
+
+
+class Tree:
+    """Tree::GetNearestNodes (utils/tree.h:73-116): exact kNN, squared L2, ascending."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lib = ctx.lib
+
+    def get_nearest_nodes(self, points_xy, queries_xy, k=1):
+        p, q = _f64(points_xy, 2), _f64(queries_xy, 2)
+        idx = np.empty((len(q), k), dtype=np.int32)
+        d2 = np.empty((len(q), k))
+        check(self.lib.pp_knn(self.ctx.h, len(p), ptr(p), len(q), ptr(q), int(k), ptr(idx), ptr(d2)))
+        return idx, d2
+
+
+class HybridAStarBatch:
+    """HybridAStar graph search for batches of independent (start, goal, seed) queries.
+
+    Single-query use mirrors PathPlannerSE2Base (pyplanning.cpp:66-71):
+        planner.set_init_state(pose); planner.set_goal_state(pose); planner.search_path(); planner.get_path()
+    """
+
+    def __init__(self, validator, params=None, max_batch=1, max_nodes=16384):
+        self.validator = validator
+        self.map = validator.map
+        self.lib = self.map.lib
+        self.params = params if params is not None else HybridAStarSearchParameters()
+        self.cparams = self.params.to_c()
+        self.max_batch, self.max_nodes = int(max_batch), int(max_nodes)
+        h = C.c_void_p()
+        check(self.lib.pp_planner_create(self.map.h, C.byref(self.cparams), self.max_batch, self.max_nodes, C.byref(h)))
+        self.h = h
+        self.num_primitives = self.lib.pp_planner_num_primitives(self.h)
+        self._init = np.zeros(3)
+        self._goal = np.zeros(3)
+        self._seed = 0
+        self._results = None
+        self.is_initialized = False
+
+    def initialize(self, nonholo_table=None):
+        """HybridAStar::Initialize (hybrid_a_star.cpp:206-235): builds the non-holonomic table on the
+        device unless one is supplied."""
+        if nonholo_table is not None:
+            t = np.ascontiguousarray(nonholo_table, dtype=np.float64)
+            check(self.lib.pp_planner_set_nonholo_table(self.h, ptr(t)))
+        else:
+            check(self.lib.pp_planner_set_nonholo_table(self.h, None))
+        self.is_initialized = True
+        return True
+
+    def nonholo_table(self):
+        cp = self.cparams
+        dims = np.zeros(3, dtype=np.int32)
+        offs = np.zeros(2)
+        lo = np.ascontiguousarray(self.map.lower)
+        up = np.ascontiguousarray(self.map.upper)
+        check(self.lib.pp_nonholo_dims(ptr(lo), ptr(up), C.byref(cp), ptr(dims), ptr(offs)))
+        t = np.empty(tuple(int(x) for x in dims))
+        check(self.lib.pp_planner_get_nonholo_table(self.h, ptr(t)))
+        return t
+
+    # -- batch API --------------------------------------------------------
+    def search_batch(self, starts, goals, seeds):
+        if not self.is_initialized:
+            # hybrid_a_star.cpp:243-246: "The algorithm has not been initialized successfully."
+            return None
+        s, g = _f64(starts, 3), _f64(goals, 3)
+        sd = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+        n = len(s)
+        res = (QueryResult * n)()
+        check(self.lib.pp_planner_search_batch(self.h, n, ptr(s), ptr(g), ptr(sd), C.cast(res, C.c_void_p)))
+        self._results = res
+        self._n = n
+        return res
+
+    def search_batch_dev(self, starts_t, goals_t, seeds_t):
+        n = starts_t.numel() // 3
+        check(self.lib.pp_planner_search_batch_dev(self.h, n, _dev_ptr(starts_t), _dev_ptr(goals_t), _dev_ptr(seeds_t)))
+        self._n = n
+
+    def fetch_results(self, n=None):
+        n = self._n if n is None else n
+        res = (QueryResult * n)()
+        check(self.lib.pp_planner_fetch_results(self.h, n, C.cast(res, C.c_void_p)))
+        self._results = res
+        return res
+
+    def last_timings(self):
+        a, b = C.c_float(), C.c_float()
+        check(self.lib.pp_planner_last_timings(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def get_path_of(self, q):
+        r = self._results[q]
+        n = r.n_path
+        poses = np.empty((n, 3))
+        kind = np.empty(n, dtype=np.int32)
+        prim = np.empty(n, dtype=np.int32)
+        length = np.empty(n)
+        tuv = np.empty((n, 3))
+        if n:
+            check(self.lib.pp_planner_get_path(self.h, q, ptr(poses), ptr(kind), ptr(prim), ptr(length), ptr(tuv)))
+        return dict(poses=poses, kind=kind, prim=prim, length=length, tuv=tuv)
+
+    def get_expanded_of(self, q):
+        r = self._results[q]
+        cells = np.empty((r.n_expanded, 3), dtype=np.int32)
+        if r.n_expanded:
+            check(self.lib.pp_planner_get_expanded(self.h, q, ptr(cells)))
+        return cells
+
+    # -- PathPlannerSE2Base-shaped single query ---------------------------
+    def set_init_state(self, pose):
+        self._init = np.asarray(pose, dtype=np.float64)
+
+    def set_goal_state(self, pose):
+        self._goal = np.asarray(pose, dtype=np.float64)
+
+    def set_seed(self, seed):
+        self._seed = int(seed)
+
+    def search_path(self):
+        res = self.search_batch([self._init], [self._goal], [self._seed])
+        if res is None:
+            return Status.FAILURE
+        return Status.SUCCESS if res[0].status == 0 else Status.FAILURE
+
+    def get_path(self):
+        """Graph-search path nodes (GetPath of the A* layer); post-processing/smoothing is out of scope."""
+        if self._results is None:
+            return np.empty((0, 3))
+        return self.get_path_of(0)["poses"]
+
+    def get_graph_search_optimal_cost(self):
+        return self._results[0].cost if self._results is not None else float("inf")
+
+    def close(self):
+        if self.h:
+            self.lib.pp_planner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

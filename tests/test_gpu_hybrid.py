@@ -1,0 +1,121 @@
+"""-m gpu: batched Hybrid-A* graph search against the CPU oracle: expanded-cell sequence bit-exact,
+path poses and cost within 1e-5, RNG-gated Reeds-Shepp expansion in step with std::mt19937_64."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_common import make_pair, valid_random_poses
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(w, ms, val, params_kw, starts, goals, seeds, max_nodes=32768, table=None, alias=True, negk=True):
+    import pathplanning_amd as pa
+    P = pa.HybridAStarSearchParameters(heading_alias=alias, negative_k_read=negk, **params_kw)
+    planner = pa.HybridAStarBatch(val, P, max_batch=len(starts), max_nodes=max_nodes)
+    planner.initialize(table)
+    res = planner.search_batch(starts, goals, seeds)
+    h = O.Hybrid(w, O.params_array(**params_kw), heading_alias=alias, negative_k_read=negk, table=planner.nonholo_table())
+    return planner, res, h
+
+
+def compare(planner, res, h, starts, goals, seeds):
+    n_ok = 0
+    for q in range(len(starts)):
+        r = h.search(starts[q], goals[q], int(seeds[q]))
+        g = res[q]
+        assert g.status == r["status"], (q, g.status, r["status"])
+        exp = planner.get_expanded_of(q)
+        assert g.n_expanded == len(r["expanded"]), (q, g.n_expanded, len(r["expanded"]))
+        assert np.array_equal(exp, r["expanded"]), q
+        assert g.n_nodes == r["n_nodes"], q
+        assert g.n_rng_draws == r["n_rng_draws"], q
+        assert g.n_rs_attempts == r["n_rs_attempts"], q
+        assert g.n_state_checks == r["n_state_checks"], (q, g.n_state_checks, r["n_state_checks"])
+        assert g.n_path_checks == r["n_path_checks"], (q, g.n_path_checks, r["n_path_checks"])
+        if r["status"] == 0:
+            n_ok += 1
+            assert abs(g.cost - r["cost"]) < 1e-5
+            path = planner.get_path_of(q)
+            assert len(path["poses"]) == len(r["path_poses"])
+            assert np.abs(path["poses"] - r["path_poses"]).max() < 1e-5
+            assert np.array_equal(path["kind"], r["path_kind"])
+            assert np.abs(path["length"] - r["path_length"]).max() < 1e-5
+            rsn = path["kind"] == 2
+            assert np.array_equal(path["prim"][rsn], r["path_rsword"][rsn])
+    return n_ok
+
+
+def test_smoke_case_from_reference_test():
+    """planner/tests/test_hybrid_a_star.cpp:9-36 on the device."""
+    import pathplanning_amd as pa
+    w = O.World(10.0, 10.0, 0.1)
+    w.update()
+    ctx = pa.Context(0)
+    ms = pa.OccupancyMapSet.from_bounds(ctx, w.lb, w.ub, 0.1)
+    ms.upload_dist2(w.d2())
+    ms.upload_occupancy(w.occ())
+    ms.upload_path_cost(w.pathcost())
+    val = pa.StateValidatorOccupancyMap(ms)
+    planner = pa.HybridAStarBatch(val)
+    assert planner.search_path() == pa.Status.FAILURE  # not initialised (hybrid_a_star.cpp:243-246)
+    planner.initialize()
+    planner.set_init_state([0.0, 0.0, 0.0])
+    planner.set_goal_state([8.0, 8.0, 0.78])
+    assert planner.search_path() == pa.Status.SUCCESS
+    path = planner.get_path()
+    assert len(path) >= 2
+    assert np.hypot(*(path[0][:2])) < 0.1
+    assert np.hypot(*(path[-1][:2] - np.array([8.0, 8.0]))) < 0.1
+    assert abs(path[-1][2] - 0.78) < math.radians(5)
+
+
+def test_batch_parity_256():
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    rng = np.random.RandomState(11)
+    n = 24
+    starts = valid_random_poses(rng, w, n)
+    goals = valid_random_poses(rng, w, n)
+    goals[0] = starts[0]  # start == goal
+    goals[1] = [100.0, 0.0, 0.0]  # goal outside the map: obstacle field stays +inf, search fails
+    seeds = np.arange(n, dtype=np.uint64) + 100
+    planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds)
+    n_ok = compare(planner, res, h, starts, goals, seeds)
+    assert n_ok >= n // 2
+
+
+def test_batch_parity_512_more_primitives_and_costs():
+    w, ms, val, ctx = make_pair(512, 12, 1)
+    rng = np.random.RandomState(12)
+    n = 8
+    starts = valid_random_poses(rng, w, n)
+    goals = valid_random_poses(rng, w, n)
+    starts[0] = [-23.04, -23.04, 0.0]
+    goals[0] = [23.04, 23.04, 0.0]  # SURVEY 8(d) config 2 query
+    seeds = np.full(n, 12345, dtype=np.uint64)
+    kw = dict(num_generated_motion=9, reverse_cost_multiplier=2.0, direction_switching_cost=0.3, voronoi_cost_multiplier=0.5)
+    planner, res, h = run_pair(w, ms, val, kw, starts, goals, seeds, max_nodes=65536)
+    assert compare(planner, res, h, starts, goals, seeds) >= 4
+
+
+def test_quirk_switches_off():
+    """'fixed' mode (no heading aliasing, wrapped heading bin in the table) also matches the oracle in the same mode."""
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    rng = np.random.RandomState(13)
+    n = 6
+    starts = valid_random_poses(rng, w, n)
+    goals = valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64)
+    planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, alias=False, negk=False, max_nodes=131072)
+    compare(planner, res, h, starts, goals, seeds)
+
+
+def test_node_capacity_is_reported():
+    import pathplanning_amd as pa
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    planner = pa.HybridAStarBatch(val, max_batch=1, max_nodes=64)
+    planner.initialize()
+    res = planner.search_batch([[-11.0, -11.0, 0.0]], [[11.0, 11.0, 0.0]], [1])
+    assert res[0].status == -4

@@ -1,0 +1,264 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+Bit-exact for integer / index / validity outputs; 1e-5 on SE(2) poses and costs (BASELINE north star)."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_common import make_pair, random_poses, valid_random_poses
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def env256():
+    return make_pair(256, 6, 3)
+
+
+@pytest.fixture(scope="module")
+def env512():
+    return make_pair(512, 12, 1)
+
+
+def test_distance_grid_matches_reference_expression(env256):
+    """(float)(sqrt((double)d2) * resolution), gvd.h:38 -- computed on the device at upload."""
+    w, ms, val, ctx = env256
+    d2 = w.d2()
+    want = (np.sqrt(d2.astype(np.float64)) * np.float64(np.float32(0.1))).astype(np.float32)
+    got = ms.download_distance()
+    assert np.array_equal(got, want)
+
+
+def test_check_states_bit_exact(env256):
+    w, ms, val, ctx = env256
+    rng = np.random.RandomState(0)
+    poses = random_poses(rng, w, 200000)
+    # edge cases: exactly on the bounds, just outside, NaN, huge theta
+    half = w.ub[0]
+    extra = np.array([[half, half, 0.0], [-half, -half, 0.0], [half + 1e-9, 0, 0], [0, -half - 1e-9, 0], [0, 0, math.pi], [0, 0, -math.pi],
+                      [0, 0, 3 * math.pi], [float("nan"), 0, 0], [0, float("nan"), 0], [1e300, 0, 0], [0, 0, 7.0], [half - 1e-12, half - 1e-12, 0]])
+    poses = np.concatenate([poses, extra])
+    got = val.is_state_valid(poses)
+    want = w.is_state_valid(poses).astype(bool)
+    assert np.array_equal(got, want)
+    assert 0.05 < want.mean() < 0.95
+
+
+def test_check_states_ragged_and_empty(env256):
+    w, ms, val, ctx = env256
+    rng = np.random.RandomState(1)
+    assert len(val.is_state_valid(np.empty((0, 3)))) == 0
+    for n in (1, 63, 64, 255, 256, 257, 1000):
+        poses = random_poses(rng, w, n)
+        assert np.array_equal(val.is_state_valid(poses), w.is_state_valid(poses).astype(bool))
+
+
+def test_check_states_device_resident_and_misaligned(env256):
+    import torch
+    w, ms, val, ctx = env256
+    rng = np.random.RandomState(2)
+    poses = random_poses(rng, w, 5000)
+    t = torch.from_numpy(np.concatenate([[0.0], poses.reshape(-1)])).cuda()
+    view = t[1:]  # 8-byte offset: the kernel's 16-byte staged path must not be taken
+    out = val.is_state_valid(view.contiguous() if False else view)
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy().astype(bool), w.is_state_valid(poses).astype(bool))
+
+
+def test_validator_tunables(env256):
+    w, ms, val, ctx = env256
+    rng = np.random.RandomState(3)
+    poses = random_poses(rng, w, 20000, margin=0.99)
+    try:
+        for r in (0.3, 2.5):
+            val.min_safe_radius = r
+            w.set_validator(r, 0.1)
+            assert np.array_equal(val.is_state_valid(poses), w.is_state_valid(poses).astype(bool))
+    finally:
+        val.min_safe_radius = 1.0
+        w.set_validator(1.0, 0.1)
+
+
+def test_check_arcs_bit_exact(env256):
+    """IsPathValid over constant-steer arcs: validity and last-valid ratio (float) identical."""
+    import pathplanning_amd as pa
+    w, ms, val, ctx = env256
+    rng = np.random.RandomState(4)
+    n = 50000
+    frm = valid_random_poses(rng, w, n)
+    P = pa.HybridAStarSearchParameters(num_generated_motion=9)
+    steer, curv, direc = P.primitives()
+    pick = rng.randint(0, len(steer), n)
+    length = rng.choice([1.5, 0.0, 3.0, 7.5], n, p=[0.7, 0.02, 0.18, 0.1])
+    v_got, l_got = val.is_path_valid(frm, curv[pick], length, direc[pick])
+    v_want, l_want = w.is_path_valid_csteer(frm, steer[pick], length, direc[pick])
+    assert np.array_equal(v_got, v_want.astype(bool))
+    assert np.array_equal(l_got, l_want)
+    assert 0.02 < (~v_got).mean() < 0.9
+
+
+def test_check_segments_bit_exact(env256):
+    w, ms, val, ctx = env256
+    rng = np.random.RandomState(5)
+    n = 30000
+    a = valid_random_poses(rng, w, n)[:, :2]
+    b = a + rng.uniform(-4, 4, (n, 2))
+    b[:50] = a[:50]  # zero-length paths
+    got = val.is_segment_valid(a, b)
+    want = w.is_path_valid_r2(a, b).astype(bool)
+    assert np.array_equal(got, want)
+
+
+def test_rollout_children_parity(env256):
+    """GetConstantSteerChild for parents x primitives: validity + discrete keys bit-exact, poses/costs 1e-5."""
+    import ctypes as C
+    import pathplanning_amd as pa
+    from pathplanning_amd._lib import check, ptr
+    w, ms, val, ctx = env256
+    for nmotion, alias in ((5, True), (37, True), (5, False)):
+        P = pa.HybridAStarSearchParameters(num_generated_motion=nmotion, heading_alias=alias)
+        steer, curv, direc = P.primitives()
+        h = O.Hybrid(w, O.params_array(num_generated_motion=nmotion), heading_alias=alias, table=np.zeros((53 if False else 27, 27, 73)))
+        assert h.P == len(curv)
+        rng = np.random.RandomState(6)
+        parents = valid_random_poses(rng, w, 3000)
+        parents[:, 2] += rng.choice([0.0, 2 * math.pi, -2 * math.pi], len(parents), p=[0.8, 0.1, 0.1])  # unwrapped headings occur in the search
+        want = h.children(parents)
+        n, Pn = len(parents), len(curv)
+        valid = np.empty((n, Pn), dtype=np.uint8)
+        pose = np.empty((n, Pn, 3))
+        key = np.empty((n, Pn, 3), dtype=np.int32)
+        cost = np.empty((n, Pn))
+        length = np.empty((n, Pn))
+        cp = P.to_c()
+        check(ms.lib.pp_rollout_children(ms.h, C.byref(cp), Pn, ptr(curv), ptr(direc), n, ptr(np.ascontiguousarray(parents)), ptr(valid), ptr(pose),
+                                         ptr(key), ptr(cost), ptr(length)))
+        assert np.array_equal(valid, want["valid"])
+        assert np.array_equal(key, want["keys"])
+        assert np.abs(pose - want["poses"]).max() < POSE_TOL
+        m = valid.astype(bool)
+        assert np.abs(cost[m] - want["cost"][m]).max() < POSE_TOL
+        assert np.abs(length[m] - want["length"][m]).max() < POSE_TOL
+        assert 0.05 < 1 - m.mean() < 0.95 or nmotion == 5
+
+
+def test_rs_solve_golden_and_random(env256):
+    import json
+    import os
+    import pathplanning_amd as pa
+    w, ms, val, ctx = env256
+    solver = pa.ReedsSheppSolver(ctx)
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reeds_shepp_vectors.json")))["vectors"]
+    starts = np.array([v["start"] for v in vec])
+    goals = np.array([v["goal"] for v in vec])
+    word, tuv, cost, seg = solver.get_optimal_path(starts, goals, 1.0)
+    for i, v in enumerate(vec):
+        assert int(word[i]) in v["accepted_words"], (i, word[i], v)
+    # random pairs, weighted costs: same word and float cost as the oracle
+    rng = np.random.RandomState(7)
+    n = 20000
+    a = np.column_stack([rng.uniform(-8, 8, n), rng.uniform(-8, 8, n), rng.uniform(-math.pi, math.pi, n)])
+    b = np.column_stack([rng.uniform(-8, 8, n), rng.uniform(-8, 8, n), rng.uniform(-math.pi, math.pi, n)])
+    for rev, fwd, sw, rmin in ((1.0, 1.0, 0.0, 2.0), (2.0, 1.0, 0.5, 2.0), (1.0, 1.5, 0.0, 1.0)):
+        word, tuv, cost, seg = solver.get_optimal_path(a, b, rmin, rev, fwd, sw)
+        wo, tuvo, costo, sego = O.rs_optimal_batch(a, b, rmin, rev, fwd, sw)
+        same = word == wo
+        # a different word is acceptable only on an exact float-cost tie broken by last-bit libm differences
+        assert same.mean() > 0.9995, same.mean()
+        assert np.allclose(cost, costo, rtol=2e-7, atol=0)
+        assert np.abs(tuv[same] - tuvo[same]).max() < 1e-9
+        assert np.abs(seg[same] - sego[same]).max() < 1e-9
+
+
+def test_nonholo_table_parity(env256):
+    import pathplanning_amd as pa
+    w, ms, val, ctx = env256
+    P = pa.HybridAStarSearchParameters()
+    table, offs = pa.NonHolonomicHeuristic.build(ctx, w.lb, w.ub, P)
+    want, offs_o = O.nonholo_build(w.lb, w.ub)
+    assert table.shape == want.shape == (27, 27, 73)
+    assert np.array_equal(offs, offs_o)
+    # entries are float costs widened to double: identical up to rare last-bit flips of the float rounding
+    diff = table != want
+    assert diff.mean() < 1e-4, diff.mean()
+    assert np.allclose(table, want, rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("goal", [(5.0, 5.0), (-11.3, 9.7), (12.79, -12.79), (0.0, 0.0), (100.0, 0.0)])
+def test_obstacle_heuristic_exact_order(env256, goal):
+    """ObstaclesHeuristic::Update: first-discovery costs are bit-identical to the sequential reference order."""
+    import pathplanning_amd as pa
+    w, ms, val, ctx = env256
+    got = pa.ObstaclesHeuristic(ms).update([goal])[0]
+    cost, explored = w.obstacle_heuristic(goal)
+    assert np.array_equal(got, cost)
+    assert np.array_equal(np.isfinite(got), explored.astype(bool))
+
+
+def test_obstacle_heuristic_many_goals_and_512(env512):
+    import pathplanning_amd as pa
+    w, ms, val, ctx = env512
+    rng = np.random.RandomState(8)
+    goals = rng.uniform(-25, 25, (6, 2))
+    got = pa.ObstaclesHeuristic(ms).update(goals)
+    for i, g in enumerate(goals):
+        cost, _ = w.obstacle_heuristic(g)
+        assert np.array_equal(got[i], cost), i
+
+
+def test_obstacle_heuristic_dense_maze_exact():
+    """A cluttered map (many small obstacles, enclosed pockets) stresses ties and the corner rule."""
+    import pathplanning_amd as pa
+    w = O.World(6.4, 6.4, 0.1)
+    rng = np.random.RandomState(9)
+    occ = np.full((w.rows, w.cols), -1, dtype=np.int32)
+    occ[rng.rand(w.rows, w.cols) < 0.28] = 0
+    occ[60:70, 60:70] = -1
+    w.set_occ(occ)
+    w.set_d2(np.full((w.rows, w.cols), 100, dtype=np.int32))
+    ctx = pa.Context(0)
+    ms = pa.OccupancyMapSet.from_bounds(ctx, w.lb, w.ub, 0.1)
+    ms.upload_occupancy(occ)
+    got = pa.ObstaclesHeuristic(ms).update([(0.05, 0.05), (3.0, -2.0)])
+    for i, g in enumerate([(0.05, 0.05), (3.0, -2.0)]):
+        cost, _ = w.obstacle_heuristic(g)
+        lit, _ = w.obstacle_heuristic(g, literal=True)
+        assert np.array_equal(cost, lit)
+        assert np.array_equal(got[i], cost)
+
+
+def test_knn_exact(env256):
+    import pathplanning_amd as pa
+    w, ms, val, ctx = env256
+    rng = np.random.RandomState(10)
+    tree = pa.Tree(ctx)
+    for npts, nq, k in ((1, 5, 1), (5, 7, 8), (3000, 700, 6), (2049, 257, 11)):
+        pts = rng.uniform(-10, 10, (npts, 2))
+        pts[npts // 2:] = np.round(pts[npts // 2:], 1)  # ties
+        q = rng.uniform(-10, 10, (nq, 2))
+        q[: nq // 2] = np.round(q[: nq // 2], 1)
+        idx, d2 = tree.get_nearest_nodes(pts, q, k)
+        dd = ((pts[None, :, :] - q[:, None, :]) ** 2)
+        dist = dd[:, :, 0] + dd[:, :, 1]
+        order = np.argsort(dist, axis=1, kind="stable")[:, :k]
+        kk = min(k, npts)
+        assert np.array_equal(idx[:, :kk], order[:, :kk])
+        assert np.array_equal(d2[:, :kk], np.take_along_axis(dist, order[:, :kk], axis=1))
+        if k > npts:
+            assert (idx[:, npts:] == -1).all() and np.isinf(d2[:, npts:]).all()
+
+
+def test_tree_fixture_cases(env256):
+    import json
+    import os
+    import pathplanning_amd as pa
+    w, ms, val, ctx = env256
+    tc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tree_cases.json")))
+    tree = pa.Tree(ctx)
+    idx, _ = tree.get_nearest_nodes(tc["points"], [tc["nearest"]["query"]], 1)
+    assert idx[0, 0] == tc["nearest"]["expect_index"]
+    idx, _ = tree.get_nearest_nodes(tc["points"], [tc["knn"]["query"]], tc["knn"]["k"])
+    assert set(idx[0]) == set(tc["knn"]["expect_indices_set"])
