@@ -63,7 +63,7 @@ def test_check_states_device_resident_and_misaligned(env256):
     poses = random_poses(rng, w, 5000)
     t = torch.from_numpy(np.concatenate([[0.0], poses.reshape(-1)])).cuda()
     view = t[1:]  # 8-byte offset: the kernel's 16-byte staged path must not be taken
-    out = val.is_state_valid(view.contiguous() if False else view)
+    out = val.is_state_valid(view)
     ctx.synchronize()
     assert np.array_equal(out.cpu().numpy().astype(bool), w.is_state_valid(poses).astype(bool))
 
@@ -121,7 +121,7 @@ def test_rollout_children_parity(env256):
     for nmotion, alias in ((5, True), (37, True), (5, False)):
         P = pa.HybridAStarSearchParameters(num_generated_motion=nmotion, heading_alias=alias)
         steer, curv, direc = P.primitives()
-        h = O.Hybrid(w, O.params_array(num_generated_motion=nmotion), heading_alias=alias, table=np.zeros((53 if False else 27, 27, 73)))
+        h = O.Hybrid(w, O.params_array(num_generated_motion=nmotion), heading_alias=alias, table=np.zeros((27, 27, 73)))
         assert h.P == len(curv)
         rng = np.random.RandomState(6)
         parents = valid_random_poses(rng, w, 3000)
@@ -142,7 +142,7 @@ def test_rollout_children_parity(env256):
         m = valid.astype(bool)
         assert np.abs(cost[m] - want["cost"][m]).max() < POSE_TOL
         assert np.abs(length[m] - want["length"][m]).max() < POSE_TOL
-        assert 0.05 < 1 - m.mean() < 0.95 or nmotion == 5
+        assert 0.005 < 1 - m.mean() < 0.95
 
 
 def test_rs_solve_golden_and_random(env256):
