@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X planner core.
+
+Workload (BASELINE.json configs[3], the config the metric is quoted on): batches of independent
+Hybrid-A* (start, goal) queries on ONE 1024x1024 occupancy map (resolution 0.1 m, 24 rectangle
+outlines), 4096 queries per GPU per step.  A step = obstacle-heuristic wavefront for every
+query's goal + the graph search of every query.  Inputs (map set, tables, starts/goals/seeds) are
+resident in HBM before the timed region.  With N GPUs every rank runs its own 4096 queries (weak
+scaling, no data-path collective); RCCL gathers the fixed-size result records at the end of each step.
+
+Prints ONE JSON line (rank 0).  Secondary metric in the same line: collision checks/s
+(IsStateValid over 2^26 streamed poses).  `roofline` is for the dominant kernel of the step;
+`cpu_baseline` is the CPU oracle (a quirk-exact port of the reference) timed on this box's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+WAVEFRONT_BYTES_PER_CELL = 9.0     # 4 B occ read + 4 B cost write + 1 B explored
+CHECK_BYTES_PER_POSE = 29.0        # 24 B pose + 4 B distance gather + 1 B result
+CHILD_BYTES = 143.0                # per expansion child
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="queries per GPU per step")
+    ap.add_argument("--cells", type=int, default=1024)
+    ap.add_argument("--obstacles", type=int, default=24)
+    ap.add_argument("--max-nodes", type=int, default=81920, help=">= number of (x, y, aliased heading) cells: no query can run out of nodes")
+    ap.add_argument("--check-poses", type=int, default=1 << 26)
+    ap.add_argument("--cpu-sample", type=int, default=192, help="queries timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    n_gpus = max(world, 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import pathplanning_amd as pa
+    from pathplanning_amd import synthetic
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = pa.Context(local_rank, stream if stream else None)
+    m = synthetic.make_map(args.cells, args.obstacles, seed=1)
+    ms, val = synthetic.upload(ctx, m)
+    params = pa.HybridAStarSearchParameters()
+    B = args.batch
+    planner = pa.HybridAStarBatch(val, params, max_batch=B, max_nodes=args.max_nodes)
+    planner.initialize()  # non-holonomic table built on the device
+
+    # queries: uniform over valid poses; every rank its own slice of the seed space
+    reach = synthetic.reachable_mask(val, m)  # drop the pockets enclosed by outline obstacles
+    starts = synthetic.sample_valid_poses(val, m, B, seed=1000 + rank, reachable=reach)
+    goals = synthetic.sample_valid_poses(val, m, B, seed=2000 + rank, reachable=reach)
+    seeds = (np.arange(B, dtype=np.uint64) + np.uint64(rank * B))
+    d_starts = torch.from_numpy(starts).to(dev)
+    d_goals = torch.from_numpy(goals).to(dev)
+    d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(dev)
+    rec = torch.zeros(B, 2, dtype=torch.float64, device=dev)  # result record gathered over RCCL: (status, cost)
+    gathered = [torch.zeros_like(rec) for _ in range(world)] if world > 1 else None
+
+    def step():
+        planner.search_batch_dev(d_starts, d_goals, d_seeds)
+        res = planner.fetch_results()
+        if world > 1:
+            st = np.array([[r.status, r.cost] for r in res], dtype=np.float64)
+            rec.copy_(torch.from_numpy(st))
+            dist.all_gather(gathered, rec)  # the only collective: final result gather
+        return res
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    wf_ms, se_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        a, b = planner.last_timings()
+        wf_ms.append(a)
+        se_ms.append(b)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    plans_per_s = B * n_gpus * args.steps / elapsed
+    n_success = sum(1 for r in res if r.status == 0)
+    n_expanded = sum(r.n_expanded for r in res)
+    n_children = n_expanded * planner.num_primitives
+    state_checks = sum(r.n_state_checks for r in res)
+
+    # ---- secondary metric: collision checks / s on streamed poses (device-resident input)
+    n_chk = args.check_poses
+    g = torch.Generator(device=dev)
+    g.manual_seed(42 + rank)
+    half = float(m["upper"][0])
+    poses = torch.empty(n_chk, 3, dtype=torch.float64, device=dev)
+    poses[:, 0].uniform_(-half, half, generator=g)
+    poses[:, 1].uniform_(-half, half, generator=g)
+    poses[:, 2].uniform_(-3.141592653589793, 3.141592653589793, generator=g)
+    out = torch.empty(n_chk, dtype=torch.uint8, device=dev)
+    lib = ctx.lib
+    from pathplanning_amd._lib import check
+    import ctypes as C
+    for _ in range(2):
+        check(lib.pp_check_states_dev(ms.h, n_chk, C.c_void_p(poses.data_ptr()), C.c_void_p(out.data_ptr())))
+    ctx.synchronize()
+    reps = 5
+    ctx.timer_start()
+    for _ in range(reps):
+        check(lib.pp_check_states_dev(ms.h, n_chk, C.c_void_p(poses.data_ptr()), C.c_void_p(out.data_ptr())))
+    chk_ms = ctx.timer_stop() / reps
+    checks_per_s = n_chk / (chk_ms * 1e-3) * n_gpus
+    chk_gbs = n_chk * CHECK_BYTES_PER_POSE / (chk_ms * 1e-3) / 1e9
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    val.count_valid_fused(n_chk, 7, cnt)
+    ctx.synchronize()
+    ctx.timer_start()
+    for _ in range(reps):
+        val.count_valid_fused(n_chk, 7, cnt)
+    fused_ms = ctx.timer_stop() / reps
+    del poses, out
+
+    # ---- roofline of the dominant kernel of the step
+    wf = float(np.mean(wf_ms))
+    se = float(np.mean(se_ms))
+    cells = ms.rows * ms.cols
+    wf_gbs = B * cells * WAVEFRONT_BYTES_PER_CELL / (wf * 1e-3) / 1e9
+    se_gbs = n_children * CHILD_BYTES / (se * 1e-3) / 1e9
+    if wf >= se:
+        roof = dict(kernel="k_wavefront", bound="hbm", achieved=wf_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=wf_gbs / HBM_PEAK_GBS, traffic=None,
+                    ms_per_launch=wf, algorithmic_bytes_per_launch=B * cells * WAVEFRONT_BYTES_PER_CELL)
+    else:
+        roof = dict(kernel="k_hybrid_search", bound="hbm", achieved=se_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=se_gbs / HBM_PEAK_GBS, traffic=None,
+                    ms_per_launch=se, algorithmic_bytes_per_launch=n_children * CHILD_BYTES)
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        try:
+            roof["traffic"] = json.load(open(tj)).get(roof["kernel"])
+        except Exception:
+            pass
+
+    # ---- CPU baseline: the oracle (port of the reference) on this box's cores, rank 0, N=1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            ow = O.World(half, half, m["resolution"])
+            ow.set_occ(m["occ"])
+            ow.set_d2(m["d2"])
+            ow.set_pathcost(m["path_cost"])
+            table = planner.nonholo_table()
+            ns = min(args.cpu_sample, B)
+            cores = min(os.cpu_count() or 1, 16)
+            secs, st, cost, nexp = O.hybrid_batch(ow, table, starts[:ns], goals[:ns], seeds[:ns], threads=cores)
+            agree = sum(1 for i in range(ns) if st[i] == res[i].status and (st[i] != 0 or abs(cost[i] - res[i].cost) < 1e-5) and nexp[i] == res[i].n_expanded)
+            cpu = dict(value=ns / secs, unit="plans/s", cores=cores, kind="port",
+                       sample="first %d of the %d benchmark queries, oracle HybridAStar::Search (heap wavefront + graph search), %d threads" % (ns, B, cores),
+                       agree_with_gpu="%d/%d" % (agree, ns))
+        except Exception as e:  # the bench line must still be printed
+            cpu = dict(value=None, unit="plans/s", cores=0, kind="port", sample="failed: %r" % (e,))
+
+    if rank == 0:
+        out = {
+            "metric": "hybrid_astar_plans_per_sec_1024x1024",
+            "value": plans_per_s,
+            "unit": "plans/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "Hybrid A* batch of %d start/goal pairs per GPU on one %dx%d map (res 0.1 m, %d rectangle outlines), P=%d constant-steer primitives + RS analytic expansion, exact-order obstacle heuristic per query" % (B, args.cells, args.cells, args.obstacles, planner.num_primitives),
+                       "queries_per_gpu": B, "grid": [ms.rows, ms.cols], "parallelism": "query-sharded x%d" % n_gpus},
+            "secondary": {"metric": "collision_checks_per_sec", "value": checks_per_s, "unit": "checks/s", "poses": n_chk, "ms": chk_ms,
+                          "achieved_GBs": chk_gbs, "hbm_frac": chk_gbs / HBM_PEAK_GBS,
+                          "fused_checks_per_sec": n_chk / (fused_ms * 1e-3) * n_gpus,
+                          "in_search_state_checks_per_sec": state_checks * n_gpus * args.steps / elapsed},
+            "kernels_ms": {"k_wavefront": wf, "k_hybrid_search": se},
+            "kernel_GBs": {"k_wavefront": wf_gbs, "k_hybrid_search": se_gbs},
+            "batch_stats": {"success": n_success, "queries": B, "expansions": n_expanded, "children": n_children},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

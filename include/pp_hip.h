@@ -185,6 +185,10 @@ int pp_planner_get_path(pp_planner* planner, int32_t q, double* poses_host, int3
 int pp_planner_get_expanded(pp_planner* planner, int32_t q, int32_t* cells_host);
 /* last batch: milliseconds spent in the wavefront kernel and in the search kernel (HIP events) */
 int pp_planner_last_timings(pp_planner* planner, float* wavefront_ms, float* search_ms);
+/* Diagnostics (never on by default): launch the stamped build of the search kernel and read, per query,
+ * 8 shader-clock sums {pop, node load, parent heuristic, children, duplicate scan, insertion, node write, RS}. */
+int pp_planner_set_profiling(pp_planner* planner, int32_t enable);
+int pp_planner_phase_cycles(pp_planner* planner, int32_t n_queries, uint64_t* cycles_host);
 
 /* ---- a14: Tree::GetNearestNodes (utils/tree.h:73-116; flann exact kNN) ------
  * points/queries: {x, y} doubles; idx/d2: [n_queries][k], ascending squared L2,

@@ -105,6 +105,8 @@ def load():
     L.pp_planner_get_path.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
     L.pp_planner_get_expanded.argtypes = [vp, C.c_int32, vp]
     L.pp_planner_last_timings.argtypes = [vp, c_fp, c_fp]
+    L.pp_planner_set_profiling.argtypes = [vp, C.c_int32]
+    L.pp_planner_phase_cycles.argtypes = [vp, C.c_int32, vp]
     L.pp_knn.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, C.c_int32, vp, vp]
     L.pp_knn_dev.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, C.c_int32, vp, vp]
     L.pp_rrt_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_int32, C.POINTER(vp), C.POINTER(RrtResult)]

@@ -91,14 +91,29 @@ __global__ void k_goal_cells(MapView m, int n, const double* __restrict__ goals,
 	cells[i] = inside_map(m, row, col) ? row * m.cols + col : -1; // WorldPositionToGridCell(bounded), heuristics.cpp:115
 }
 
+// kProfile: diagnostic build only -- accumulates shader-clock cycles per phase into `prof`
+// (8 words per query); the product path launches kProfile = false, where no stamp executes.
+enum { PH_POP = 0, PH_LOAD, PH_HEUR, PH_CHILD, PH_DUP, PH_INSERT, PH_WRITE, PH_RS, PH_COUNT };
+template <bool kProfile>
 __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries, const double* __restrict__ starts, const double* __restrict__ goals,
 	const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase, HeapEntry* __restrict__ heapBase,
-	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, DevResult* __restrict__ results)
+	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, DevResult* __restrict__ results,
+	unsigned long long* __restrict__ prof)
 {
 	const int q = blockIdx.x;
 	if (q >= nQueries)
 		return;
 	const int lane = threadIdx.x;
+	unsigned long long phase[PH_COUNT] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	unsigned long long tlast = 0;
+	if (kProfile)
+		tlast = clock64();
+#define PP_STAMP(i)                                \
+	if (kProfile) {                                \
+		const unsigned long long now_ = clock64(); \
+		phase[i] += now_ - tlast;                  \
+		tlast = now_;                              \
+	}
 
 	__shared__ unsigned long long mt[Mt64::N];
 	// per-child staging (one slot per lane)
@@ -184,6 +199,7 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 		if (lane == 0)
 			s_heapSize = heapSize;
 		__syncthreads();
+		PP_STAMP(PH_POP);
 		const int ni = (int)top.node;
 		const Node parent = nodes[ni];
 		if (parent.dead)
@@ -206,8 +222,12 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 		int pix, piy, pit;
 		discretize_pose(ppose, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, pix, piy, pit);
 
+		PP_STAMP(PH_LOAD);
 		// RS gate input: heuristic of the node being expanded (hybrid_a_star.cpp:81)
 		const double hCost = combined_heuristic(A.heur, m, field, goal, ppose);
+		if (kProfile && hCost == -1.0)
+			phase[PH_HEUR] += 1; // keeps the value live ahead of the stamp
+		PP_STAMP(PH_HEUR);
 
 		bool capacity = false;
 		// ---- constant-steer children, reference order p = 2*deltaIndex + direction (hybrid_a_star.cpp:65-77)
@@ -261,6 +281,7 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 			c_state[lane] = ok ? keymap[key] : 0u;
 			c_node[lane] = -1;
 			__syncthreads();
+			PP_STAMP(PH_CHILD);
 			// does an EARLIER valid child of this batch share my cell?  (then my prefetched state may be stale)
 			{
 				bool dup = false;
@@ -271,6 +292,7 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 				c_dup[lane] = dup ? 1 : 0;
 			}
 			__syncthreads();
+			PP_STAMP(PH_DUP);
 			// ---- sequential insertion in child order (lane 0): a_star.h:391-402 + hybrid_a_star.h:199-205
 			if (lane == 0) {
 				int hs = s_heapSize, nn = s_nNodes;
@@ -315,6 +337,7 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 				s_seq = seq;
 			}
 			__syncthreads();
+			PP_STAMP(PH_INSERT);
 			// ---- every lane writes the node record of its own child
 			if (c_node[lane] >= 0) {
 				Node nd;
@@ -331,6 +354,7 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 				nodes[c_node[lane]] = nd;
 			}
 			__syncthreads();
+			PP_STAMP(PH_WRITE);
 			if (s_status == -4) {
 				capacity = true;
 				break;
@@ -477,7 +501,12 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 		heapSize = s_heapSize;
 		nNodes = s_nNodes;
 		__syncthreads();
+		PP_STAMP(PH_RS);
 	}
+	if (kProfile && lane == 0)
+		for (int i = 0; i < PH_COUNT; i++)
+			prof[(size_t)q * PH_COUNT + i] = phase[i];
+#undef PP_STAMP
 
 	// lane-local counters -> totals
 	for (int off = 32; off > 0; off >>= 1) {
@@ -534,6 +563,8 @@ struct pp_planner {
 	uint32_t* expanded = nullptr;
 	RsLogEntry* rsLogs = nullptr;
 	DevResult* results = nullptr;
+	unsigned long long* prof = nullptr; // diagnostic phase cycles, [maxBatch][PH_COUNT]
+	bool profile = false;
 	double *dStarts = nullptr, *dGoals = nullptr;
 	uint64_t* dSeeds = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -550,7 +581,7 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
-	void* ptrs[] = { p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->dStarts,
+	void* ptrs[] = { p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -682,6 +713,7 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 	alloc((void**)&p->expanded, B * N * 4);
 	alloc((void**)&p->rsLogs, B * kRsLogCap * sizeof(RsLogEntry));
 	alloc((void**)&p->results, B * sizeof(DevResult));
+	alloc((void**)&p->prof, B * PH_COUNT * sizeof(unsigned long long));
 	alloc((void**)&p->dStarts, B * 24);
 	alloc((void**)&p->dGoals, B * 24);
 	alloc((void**)&p->dSeeds, B * 8);
@@ -769,8 +801,12 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, planner->goalCells, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
 		planner->wfError));
 	PP_HIP_TRY(hipEventRecord(planner->e1, s));
-	hipLaunchKernelGGL(k_hybrid_search, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-		planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->results);
+	if (planner->profile)
+		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->results, planner->prof);
+	else
+		hipLaunchKernelGGL(k_hybrid_search<false>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->results, planner->prof);
 	PP_HIP_TRY(hipGetLastError());
 	PP_HIP_TRY(hipEventRecord(planner->e2, s));
 	planner->lastBatch = n_queries;
@@ -818,6 +854,27 @@ int pp_planner_search_batch(pp_planner* planner, int32_t n_queries, const double
 	if (int rc = pp_planner_search_batch_dev(planner, n_queries, planner->dStarts, planner->dGoals, planner->dSeeds))
 		return rc;
 	return pp_planner_fetch_results(planner, n_queries, results_host);
+}
+
+int pp_planner_set_profiling(pp_planner* planner, int32_t enable)
+{
+	if (!planner) {
+		set_error("null planner");
+		return PP_ERR_INVALID;
+	}
+	planner->profile = enable != 0;
+	return PP_OK;
+}
+
+int pp_planner_phase_cycles(pp_planner* planner, int32_t n_queries, uint64_t* cycles_host)
+{
+	if (!planner || n_queries < 0 || n_queries > planner->lastBatch || !cycles_host) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	PP_HIP_TRY(hipMemcpy(cycles_host, planner->prof, (size_t)n_queries * PH_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return PP_OK;
 }
 
 int pp_planner_last_timings(pp_planner* planner, float* wavefront_ms, float* search_ms)
