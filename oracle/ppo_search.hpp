@@ -1092,7 +1092,10 @@ inline RRTResult RRTStar(const R2Problem& prob, const RRTParams& p, const Point2
 		}
 		// rrt_star.h:100: Extend(newState, bestParentNode); a null parent falls
 		// back to the nearest node inside Tree::Extend (tree.h:131).
-		int src = bestParent >= 0 ? bestParent : tree.Nearest(newState, 1)[0];
+		// tree.h:124-133: an existing state returns its node before any nearest-node query
+		int src = bestParent;
+		if (src < 0 && tree.index.find({ newState.x, newState.y }) == tree.index.end())
+			src = tree.Nearest(newState, 1)[0];
 		int newNode = tree.Extend(newState, src);
 		tree.cost[newNode] = bestCost; // rrt_star.h:101 (also overwrites an existing node's cost)
 		if (newState.x == goal.x && newState.y == goal.y) { // rrt_star.h:136-139, exact equality

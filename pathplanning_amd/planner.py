@@ -451,3 +451,64 @@ class HybridAStarBatch:
             self.close()
         except Exception:
             pass
+
+
+class _RRTBase:
+    """RRT / RRTStar over R2 (algo/rrt.h, algo/rrt_star.h): the whole sequential loop runs on the device.
+    validator=None reproduces StateValidatorFree (planner/tests/test_rrt*.cpp)."""
+    _star = 0
+
+    def __init__(self, ctx, lower, upper, validator=None, max_iteration=None, max_number_tree_node=10000, max_connection_distance=0.1,
+                 goal_bias=0.05):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.lower = np.ascontiguousarray(lower, dtype=np.float64)[:2].copy()
+        self.upper = np.ascontiguousarray(upper, dtype=np.float64)[:2].copy()
+        self.validator = validator
+        if max_iteration is None:
+            max_iteration = 10000 if self._star else 100  # RRTStarParameters / RRTParameters defaults
+        self.max_iteration = max_iteration
+        self.max_number_tree_node = max_number_tree_node
+        self.max_connection_distance = max_connection_distance
+        self.goal_bias = goal_bias
+        self._init = np.zeros(2)
+        self._goal = np.zeros(2)
+        self._seed = 0
+        self.result = None
+
+    def set_init_state(self, p):
+        self._init = np.ascontiguousarray(p, dtype=np.float64)[:2].copy()
+
+    def set_goal_state(self, p):
+        self._goal = np.ascontiguousarray(p, dtype=np.float64)[:2].copy()
+
+    def set_seed(self, seed):
+        self._seed = int(seed)
+
+    def search_path(self):
+        params = np.array([self.max_iteration, self.max_number_tree_node, self.max_connection_distance, self.goal_bias], dtype=np.float64)
+        h = C.c_void_p()
+        res = _lib.RrtResult()
+        mh = self.validator.map.h if self.validator is not None else None
+        check(self.lib.pp_rrt_run(self.ctx.h, mh, ptr(self.lower), ptr(self.upper), ptr(params), ptr(self._init), ptr(self._goal),
+                                  C.c_uint64(self._seed), self._star, C.byref(h), C.byref(res)))
+        nodes = np.empty((res.n_nodes, 2))
+        parents = np.empty(res.n_nodes, dtype=np.int32)
+        costs = np.empty(res.n_nodes)
+        path = np.empty((res.n_path, 2))
+        check(self.lib.pp_rrt_get(h, ptr(nodes), ptr(parents), ptr(costs), ptr(path)))
+        self.lib.pp_rrt_destroy(h)
+        self.result = dict(status=res.status, nodes=nodes, parents=parents, costs=costs, path=path, iterations=res.iterations,
+                           n_knn=res.n_knn_queries, n_edge_checks=res.n_edge_checks)
+        return Status.SUCCESS if res.status == 0 else Status.FAILURE
+
+    def get_path(self):
+        return self.result["path"] if self.result is not None else np.empty((0, 2))
+
+
+class RRT(_RRTBase):
+    _star = 0
+
+
+class RRTStar(_RRTBase):
+    _star = 1

@@ -1,0 +1,76 @@
+"""-m gpu: device RRT / RRT* (whole loop on the GPU) against the CPU oracle: identical trees."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_common import make_pair
+
+pytestmark = pytest.mark.gpu
+SMOKE = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "smoke_cases.json")))
+
+
+def same_tree(got, want):
+    assert got["status"] == want["status"]
+    assert got["iterations"] == want["iterations"]
+    assert len(got["nodes"]) == len(want["nodes"])
+    assert np.array_equal(got["parents"], want["parents"])
+    assert np.abs(got["nodes"] - want["nodes"]).max() < 1e-9 if len(got["nodes"]) else True
+    fin = np.isfinite(want["costs"])
+    assert np.array_equal(np.isfinite(got["costs"]), fin)
+    assert np.abs(got["costs"][fin] - want["costs"][fin]).max() < 1e-9
+    assert got["n_knn"] == want["n_knn"]
+    assert got["n_edge_checks"] == want["n_edge_checks"]
+    assert len(got["path"]) == len(want["path"])
+    if len(want["path"]):
+        assert np.abs(got["path"] - want["path"]).max() < 1e-9
+
+
+def test_reference_smoke_cases_free_space():
+    """planner/tests/test_rrt.cpp / test_rrt_star.cpp configurations."""
+    import pathplanning_amd as pa
+    ctx = pa.Context(0)
+    c = SMOKE["rrt"]
+    for seed in range(6):
+        r = pa.RRT(ctx, c["bounds"][0], c["bounds"][1])
+        r.set_init_state(c["start"])
+        r.set_goal_state(c["goal"])
+        r.set_seed(seed)
+        r.search_path()
+        want = O.rrt(None, c["bounds"][0], c["bounds"][1], c["start"], c["goal"], seed, star=False)
+        same_tree(r.result, want)
+    c = SMOKE["rrt_star"]
+    n_ok = 0
+    for seed in range(4):
+        r = pa.RRTStar(ctx, c["bounds"][0], c["bounds"][1])
+        r.set_init_state(c["start"])
+        r.set_goal_state(c["goal"])
+        r.set_seed(seed)
+        st = r.search_path()
+        want = O.rrt(None, c["bounds"][0], c["bounds"][1], c["start"], c["goal"], seed, star=True, max_iteration=10000, max_nodes=10000)
+        same_tree(r.result, want)
+        if st == pa.Status.SUCCESS:
+            n_ok += 1
+            path = r.get_path()
+            assert np.hypot(*(path[0] - np.array(c["start"]))) < c["spatial_tolerance"]
+            assert np.hypot(*(path[-1] - np.array(c["goal"]))) < c["spatial_tolerance"]
+    assert n_ok >= 1
+
+
+def test_rrt_star_on_occupancy_map():
+    """SURVEY 8(d) config 3 shape (scaled down): R2 occupancy validator, kNN + choose-parent + edge checks."""
+    import pathplanning_amd as pa
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    lb, ub = w.lb[:2], w.ub[:2]
+    for seed, star in ((1, True), (2, True), (3, False)):
+        cls = pa.RRTStar if star else pa.RRT
+        r = cls(ctx, lb, ub, validator=val, max_iteration=6000, max_number_tree_node=6000, max_connection_distance=0.512, goal_bias=0.05)
+        r.set_init_state([-11.0, -11.0])
+        r.set_goal_state([11.0, 11.0])
+        r.set_seed(seed)
+        r.search_path()
+        want = O.rrt(w, lb, ub, [-11.0, -11.0], [11.0, 11.0], seed, star=star, max_iteration=6000, max_nodes=6000, max_connection=0.512, goal_bias=0.05)
+        same_tree(r.result, want)
+        assert len(want["nodes"]) > 100
