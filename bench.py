@@ -72,20 +72,18 @@ def main():
     reach = synthetic.reachable_mask(val, m)  # drop the pockets enclosed by outline obstacles
     starts = synthetic.sample_valid_poses(val, m, B, seed=1000 + rank, reachable=reach)
     goals = synthetic.sample_valid_poses(val, m, B, seed=2000 + rank, reachable=reach)
-    seeds = (np.arange(B, dtype=np.uint64) + np.uint64(rank * B))
+    from pathplanning_amd import sharding
+    my_ids = sharding.shard_indices(B * max(world, 1), rank, max(world, 1))  # global query ids owned by this rank (block-cyclic)
+    seeds = my_ids.astype(np.uint64)
     d_starts = torch.from_numpy(starts).to(dev)
     d_goals = torch.from_numpy(goals).to(dev)
     d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(dev)
-    rec = torch.zeros(B, 2, dtype=torch.float64, device=dev)  # result record gathered over RCCL: (status, cost)
-    gathered = [torch.zeros_like(rec) for _ in range(world)] if world > 1 else None
-
     def step():
         planner.search_batch_dev(d_starts, d_goals, d_seeds)
         res = planner.fetch_results()
         if world > 1:
-            st = np.array([[r.status, r.cost] for r in res], dtype=np.float64)
-            rec.copy_(torch.from_numpy(st))
-            dist.all_gather(gathered, rec)  # the only collective: final result gather
+            # the only collective: gather of the fixed-size result records (RCCL all_gather)
+            sharding.gather_records(sharding.records_from_results(res, B), B * world, rank, world, device=dev)
         return res
 
     def sync_all():
