@@ -124,6 +124,43 @@ struct Arc {
 	}
 };
 
+/// The same arc with sin/cos of the initial heading supplied (they are stored with the node that is
+/// being expanded) and sin/cos of the interpolated heading returned: one sincos per sample instead of
+/// four libm calls.  A zero travelled distance returns the initial pose (x + 1/k*(sin t - sin t) = x).
+struct ArcSC {
+	Pose init;
+	double sinF, cosF;
+	double kappa;
+	double length;
+	int backward;
+	PPD_INLINE Pose interpolate_sc(double ratio, double& s, double& c) const
+	{
+		double d = length * ratio;
+		if (backward)
+			d = -d;
+		Pose to = init;
+		s = sinF;
+		c = cosF;
+		if (d == 0.0)
+			return to;
+		if (fabs(kappa) > 1e-9) {
+			to.t += d * kappa;
+			sincos(to.t, &s, &c);
+			to.x += 1 / kappa * (s - sinF);
+			to.y += 1 / kappa * (-c + cosF);
+		} else {
+			to.x += d * cosF;
+			to.y += d * sinF;
+		}
+		return to;
+	}
+	PPD_INLINE Pose interpolate(double ratio) const
+	{
+		double s, c;
+		return interpolate_sc(ratio, s, c);
+	}
+};
+
 /// An R2 segment seen as an SE2 path with theta = 0 (paths/path_r2.cpp:11-16)
 struct Segment {
 	double x0, y0, x1, y1;

@@ -21,17 +21,19 @@ using namespace ppd;
 
 namespace {
 
-struct Node { // 64 bytes
+struct Node { // 96 bytes
 	double x, y, t;
 	double pathCost, totalCost;
-	double length;   // arc length after truncation / RS path length
+	double length;     // arc length after truncation / RS path length
+	double h;          // combined heuristic of this pose (reused as the RS gate input when it is expanded)
+	double sinT, cosT; // sin / cos of t (reused as the initial-heading terms of the children's arcs)
 	int32_t parent;
-	uint32_t key;    // packed discrete pose
-	int16_t action;  // -1 root, 0..P-1 constant-steer primitive, 1000 + word for Reeds-Shepp
-	uint8_t dead;    // removed from the open list by ProcessPossibleShortcut
-	uint8_t pad[5];
+	uint32_t key;      // packed discrete pose
+	int16_t action;    // -1 root, 0..P-1 constant-steer primitive, 1000 + word for Reeds-Shepp
+	uint8_t dead;      // removed from the open list by ProcessPossibleShortcut
+	uint8_t pad[13];
 };
-static_assert(sizeof(Node) == 64, "Node layout");
+static_assert(sizeof(Node) == 96, "Node layout");
 
 struct RsLogEntry {
 	int32_t node, word;
@@ -93,7 +95,26 @@ __global__ void k_goal_cells(MapView m, int n, const double* __restrict__ goals,
 
 // kProfile: diagnostic build only -- accumulates shader-clock cycles per phase into `prof`
 // (8 words per query); the product path launches kProfile = false, where no stamp executes.
+// One wave per block: LDS operations of a wave complete in program order, so lanes only need the
+// compiler not to reorder around the hand-off.  __syncthreads() would also drain every outstanding
+// HBM store (s_waitcnt vmcnt(0)), ~1-2k cycles each time.
+__device__ __forceinline__ void wave_lds_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+/// waits until this wave's global stores are visible to its other lanes' loads
+__device__ __forceinline__ void wave_vmem_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	__builtin_amdgcn_s_waitcnt(0);
+	__builtin_amdgcn_wave_barrier();
+}
+
 enum { PH_POP = 0, PH_LOAD, PH_HEUR, PH_CHILD, PH_DUP, PH_INSERT, PH_WRITE, PH_RS, PH_COUNT };
+constexpr int kSlots = 65; // staging: one slot per lane + one for the Reeds-Shepp child
+constexpr int kRsSlot = 64;
+
 template <bool kProfile>
 __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries, const double* __restrict__ starts, const double* __restrict__ goals,
 	const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase, HeapEntry* __restrict__ heapBase,
@@ -116,13 +137,14 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 	}
 
 	__shared__ unsigned long long mt[Mt64::N];
-	// per-child staging (one slot per lane)
-	__shared__ double c_x[64], c_y[64], c_t[64], c_cost[64], c_total[64], c_len[64];
-	__shared__ uint32_t c_key[64], c_state[64];
-	__shared__ uint8_t c_valid[64], c_dup[64];
-	__shared__ int32_t c_node[64];
-	__shared__ int s_heapSize, s_nNodes, s_status;
-	__shared__ unsigned int s_seq;
+	// staging of the children of the node being expanded; kept until the next expansion so that a
+	// child popped right away is read back from LDS instead of HBM
+	__shared__ double c_x[kSlots], c_y[kSlots], c_t[kSlots], c_cost[kSlots], c_total[kSlots], c_len[kSlots], c_h[kSlots], c_sin[kSlots], c_cos[kSlots];
+	__shared__ uint32_t c_key[kSlots], c_state[kSlots];
+	__shared__ uint8_t c_valid[kSlots];
+	__shared__ int16_t c_action[kSlots];
+	__shared__ int s_rsChecks;
+	__shared__ HeapEntry s_spill[16]; // entries that left the front buffer during this expansion
 
 	const MapView& m = A.m;
 	const int P = A.prims.n;
@@ -141,7 +163,7 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 	// ---- InitializeSearch, a_star.h:350-364
 	{
 		const size_t n = A.ks.size();
-		const size_t n4 = n / 4; // keymap base is 16-byte aligned when n % 4 == 0; otherwise scalar
+		const size_t n4 = n / 4;
 		if ((((uintptr_t)keymap) & 15) == 0) {
 			uint4 z = { 0, 0, 0, 0 };
 			for (size_t i = lane; i < n4; i += 64)
@@ -153,80 +175,178 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 				keymap[i] = 0;
 		}
 	}
-	if (lane == 0) {
+	int myNode = -1; // node index of the child staged in this lane's slot (-1: none / not pushed)
+	int rsNode = -1; // same for the Reeds-Shepp slot (wave-uniform)
+	if (lane == 0)
 		Mt64::seed(mt, seeds[q]);
+	FrontLane front;
+	front_clear(front);
+	int frontCount = 0;
+	int heapSize = 0;
+	HeapEntry heapTop;
+	heapTop.ckey = ~0ull;
+	heapTop.nseq = ~0u;
+	heapTop.node = 0;
+	int nNodes = 1;
+	unsigned int seq = 1;
+	{
+		double rs_, rc_;
+		sincos(start.t, &rs_, &rc_);
 		int ix, iy, it;
 		discretize_pose(start, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
 		uint32_t key = kNoKey;
 		const bool ok = A.ks.pack(ix, iy, it, key);
-		Node root;
-		root.x = start.x;
-		root.y = start.y;
-		root.t = start.t;
-		root.pathCost = 0.0;
-		root.totalCost = 0.0;
-		root.length = 0.0;
-		root.parent = -1;
-		root.key = ok ? key : kNoKey;
-		root.action = -1;
-		root.dead = 0;
-		nodes[0] = root;
+		if (lane == 0) {
+			Node root;
+			root.x = start.x;
+			root.y = start.y;
+			root.t = start.t;
+			root.pathCost = 0.0;
+			root.totalCost = 0.0;
+			root.length = 0.0;
+			root.h = combined_heuristic_sc(A.heur, m, field, goal, start, rs_, rc_);
+			root.sinT = rs_;
+			root.cosT = rc_;
+			root.parent = -1;
+			root.key = ok ? key : kNoKey;
+			root.action = -1;
+			root.dead = 0;
+			nodes[0] = root;
+			if (ok)
+				keymap[key] = kExplored; // the root is inserted in the explored set at init (a_star.h:361)
+		}
 		HeapEntry e;
 		e.ckey = cost_key(0.0);
 		e.nseq = 0xFFFFFFFFu;
 		e.node = 0;
-		heap[0] = e;
-		if (ok)
-			keymap[key] = kExplored; // the root is inserted in the explored set at init (a_star.h:361)
-		s_heapSize = 1;
-		s_nNodes = 1;
-		s_seq = 1;
-		s_status = 1; // 1 = running
+		HeapEntry sp;
+		front_insert(front, frontCount, e, lane, sp);
 	}
 	int mtIdx = Mt64::N; // engine freshly seeded: first draw twists
 	__syncthreads();
 
-	int heapSize = 1, nNodes = 1;
 	int nExpanded = 0, nRngDraws = 0, nRsAttempts = 0, nRsLog = 0;
 	long long laneStateChecks = 0, lanePathChecks = 0; // this lane's arcs
 	long long rsStateChecks = 0, rsPathChecks = 0;     // wave-uniform (Reeds-Shepp children)
 	int status = -1, solutionNode = -1;
 	double solutionCost = __builtin_huge_val();
 
-	// ---- SearchPath main loop, a_star.h:337-345
-	while (heapSize > 0) {
-		const HeapEntry top = heap_pop_wave(heap, heapSize, lane);
-		if (lane == 0)
-			s_heapSize = heapSize;
+	// Entries that leave the front buffer are staged in LDS and flushed to the HBM heap in one go:
+	// the flush loads all their heap parents in parallel (one memory round trip); only when some
+	// entry really has to move up does lane 0 fall back to one-by-one sift-ups.
+	int nSpill = 0;
+	auto flush_spills = [&]() {
+		if (nSpill == 0)
+			return;
 		__syncthreads();
+		bool needSift = false;
+		HeapEntry mine;
+		if (lane < nSpill) {
+			mine = s_spill[lane];
+			const int pos = heapSize + lane;
+			if (pos > 0) {
+				const int par = (pos - 1) >> 6;
+				// a parent slot that is itself being appended in this flush is compared by the fallback
+				if (par >= heapSize)
+					needSift = true;
+				else {
+					const HeapEntry pe = heap[par];
+					needSift = heap_before(mine, pe);
+				}
+			}
+		}
+		if (__ballot(needSift)) {
+			if (lane == 0) {
+				int hs = heapSize;
+				for (int i = 0; i < nSpill; i++)
+					heap_push(heap, hs, s_spill[i]);
+			}
+		} else if (lane < nSpill) {
+			heap[heapSize + lane] = mine;
+		}
+		for (int i = 0; i < nSpill; i++) {
+			const HeapEntry e = s_spill[i];
+			if (heapSize + i == 0 || heap_before(e, heapTop))
+				heapTop = e;
+		}
+		heapSize += nSpill;
+		nSpill = 0;
+		__syncthreads();
+	};
+	auto spill = [&](const HeapEntry& e) {
+		if (lane == 0)
+			s_spill[nSpill] = e;
+		nSpill++;
+		if (nSpill == 16)
+			flush_spills();
+	};
+
+	// ---- SearchPath main loop, a_star.h:337-345
+	while (frontCount > 0 || heapSize > 0 || nSpill > 0) {
+		flush_spills();
+		HeapEntry top;
+		const bool fromFront = frontCount > 0 && (heapSize == 0 || key_before(lane_read64(front.ckey, 0), lane_read(front.nseq, 0), heapTop.ckey, heapTop.nseq));
+		if (fromFront) {
+			top = front_pop(front, frontCount, lane);
+		} else {
+			__syncthreads(); // earlier heap writes
+			top = heap_pop_wave(heap, heapSize, lane, heapTop);
+			__syncthreads();
+		}
 		PP_STAMP(PH_POP);
 		const int ni = (int)top.node;
-		const Node parent = nodes[ni];
-		if (parent.dead)
+		// ---- the popped node: from the staging of the previous expansion when it is one of its children
+		double px, py, pt, pPathCost, pH, pSin, pCos;
+		uint32_t pKey;
+		bool pDead = false;
+		{
+			const unsigned long long hit = __ballot(myNode == ni);
+			int slot = hit ? (__ffsll((long long)hit) - 1) : (rsNode == ni ? kRsSlot : -1);
+			if (slot >= 0) {
+				px = c_x[slot];
+				py = c_y[slot];
+				pt = c_t[slot];
+				pPathCost = c_cost[slot];
+				pH = c_h[slot];
+				pSin = c_sin[slot];
+				pCos = c_cos[slot];
+				pKey = c_key[slot];
+			} else {
+				const Node nd = nodes[ni];
+				px = nd.x;
+				py = nd.y;
+				pt = nd.t;
+				pPathCost = nd.pathCost;
+				pH = nd.h;
+				pSin = nd.sinT;
+				pCos = nd.cosT;
+				pKey = nd.key;
+				pDead = nd.dead != 0;
+			}
+		}
+		wave_lds_sync(); // staging is about to be overwritten
+		if (pDead)
 			continue; // entry of a node replaced by ProcessPossibleShortcut
-		const Pose ppose = { parent.x, parent.y, parent.t };
+		const Pose ppose = { px, py, pt };
 		if (identical_poses(ppose, goal)) { // IsSolution, hybrid_a_star.h:193-196
 			status = 0;
 			solutionNode = ni;
-			solutionCost = parent.pathCost;
+			solutionCost = pPathCost;
 			break;
 		}
 		// ---- Expand, a_star.h:377-409
 		if (lane == 0) {
-			if (parent.key != kNoKey)
-				keymap[parent.key] = kExplored;
+			if (pKey != kNoKey)
+				keymap[pKey] = kExplored; // children in the parent's own cell are caught by a key compare below
 			expanded[nExpanded] = (uint32_t)ni;
 		}
-		__syncthreads(); // children landing in the parent's own cell must read it as explored
+		rsNode = -1;
 		nExpanded++;
 		int pix, piy, pit;
 		discretize_pose(ppose, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, pix, piy, pit);
-
 		PP_STAMP(PH_LOAD);
-		// RS gate input: heuristic of the node being expanded (hybrid_a_star.cpp:81)
-		const double hCost = combined_heuristic(A.heur, m, field, goal, ppose);
-		if (kProfile && hCost == -1.0)
-			phase[PH_HEUR] += 1; // keeps the value live ahead of the stamp
+		// RS gate input (hybrid_a_star.cpp:81): the heuristic of this pose was computed when the node was created
+		const double hCost = pH;
 		PP_STAMP(PH_HEUR);
 
 		bool capacity = false;
@@ -234,131 +354,168 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 		for (int base = 0; base < P; base += 64) {
 			const int p = base + lane;
 			bool ok = false;
-			uint32_t key = kNoKey;
+			uint32_t key = kNoKey, st = 0u;
 			Pose child = ppose;
-			double cost = 0.0, total = 0.0, len = 0.0;
+			double cs = pSin, cc = pCos;
+			double gcost = 0.0, total = 0.0, len = 0.0, hh = 0.0;
 			if (p < P) {
-				Arc a;
+				ArcSC a;
 				a.init = ppose;
+				a.sinF = pSin;
+				a.cosF = pCos;
 				a.kappa = A.prims.kappa[p];
 				a.length = A.rp.arcLength;
 				a.backward = A.prims.backward[p];
-				child = a.interpolate(1.0);
+				child = a.interpolate_sc(1.0, cs, cc);
 				int ix, iy, it;
 				discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+				PP_STAMP(PH_HEUR); // [diagnostic: endpoint]
+				// look-ups of the full-length child are issued before the validity march so that their
+				// latency overlaps it (they are redone only when the arc gets truncated)
+				bool packed = A.ks.pack(ix, iy, it, key);
+				if (packed)
+					st = keymap[key];
+				hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
 				float lastValidRatio;
 				int checks = 0;
 				ok = true;
 				lanePathChecks++;
-				if (!is_path_valid(m, a, a.init, lastValidRatio, checks)) {
-					child = a.interpolate((double)lastValidRatio);
+				const bool pathValid = is_path_valid(m, a, a.init, lastValidRatio, checks);
+				PP_STAMP(PH_DUP); // [diagnostic: look-up issue + validity march]
+				if (!pathValid) {
+					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
+					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
 					a.length *= (double)lastValidRatio;
 					discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
 					if (ix == pix && iy == piy && it == pit)
 						ok = false;
+					else {
+						packed = A.ks.pack(ix, iy, it, key);
+						if (packed)
+							st = keymap[key];
+						hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
+					}
 				}
 				laneStateChecks += checks;
 				if (ok) {
 					const double pathCost = (a.backward ? A.rp.reverseMult : A.rp.forwardMult) * a.length;
 					const double voro = voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
-					cost = pathCost + 0.0 + voro; // switching cost is always 0 (hybrid_a_star.cpp:142)
+					const double cost = pathCost + 0.0 + voro; // switching cost is always 0 (hybrid_a_star.cpp:142)
 					len = a.length;
-					const double childPathCost = parent.pathCost + cost;
-					total = childPathCost + combined_heuristic(A.heur, m, field, goal, child); // a_star.h:387-388
-					cost = childPathCost;
-					if (!A.ks.pack(ix, iy, it, key))
+					gcost = pPathCost + cost;
+					total = gcost + hh; // a_star.h:387-388
+					if (!packed)
 						ok = false; // outside the key map (cannot happen for poses inside the bounds)
 				}
 			}
-			c_valid[lane] = ok ? 1 : 0;
+			if (ok && key == pKey)
+				st = kExplored; // the parent's cell was marked explored just above (a_star.h:381)
+			// does an EARLIER valid child of this batch share my cell?  (then my prefetched state may be stale)
+			bool dup = false;
+			const int cnt = min(64, P - base);
+			for (int e = 0; e < cnt; e++) {
+				const uint32_t ke = lane_read(key, e);
+				const int ve = (int)lane_read(ok ? 1u : 0u, e);
+				if (e < lane && ve && ke == key)
+					dup = true;
+			}
+			// staging for the pop that follows (read back from LDS when one of these children is expanded next)
 			c_key[lane] = key;
 			c_x[lane] = child.x;
 			c_y[lane] = child.y;
 			c_t[lane] = child.t;
-			c_cost[lane] = cost;
+			c_cost[lane] = gcost;
 			c_total[lane] = total;
 			c_len[lane] = len;
-			c_state[lane] = ok ? keymap[key] : 0u;
-			c_node[lane] = -1;
-			__syncthreads();
+			c_h[lane] = hh;
+			c_sin[lane] = cs;
+			c_cos[lane] = cc;
+			myNode = -1;
+			wave_lds_sync();
 			PP_STAMP(PH_CHILD);
-			// does an EARLIER valid child of this batch share my cell?  (then my prefetched state may be stale)
-			{
-				bool dup = false;
-				if (ok)
-					for (int e = 0; e < lane; e++)
-						if (c_valid[e] && c_key[e] == key)
-							dup = true;
-				c_dup[lane] = dup ? 1 : 0;
-			}
-			__syncthreads();
-			PP_STAMP(PH_DUP);
-			// ---- sequential insertion in child order (lane 0): a_star.h:391-402 + hybrid_a_star.h:199-205
-			if (lane == 0) {
-				int hs = s_heapSize, nn = s_nNodes;
-				unsigned int seq = s_seq;
-				const int cnt = min(64, P - base);
-				for (int c = 0; c < cnt; c++) {
-					if (!c_valid[c])
-						continue;
-					const uint32_t ckey = c_key[c];
-					const uint32_t st = c_dup[c] ? keymap[ckey] : c_state[c];
-					bool push = false;
-					if (st == 0u) {
-						push = true; // !inFrontier && !inExplored
-					} else if (st != kExplored) {
-						// in the open list: replace only if the poses are identical and the new path is strictly cheaper
-						const Node fn = nodes[st - 1];
-						const Pose fp = { fn.x, fn.y, fn.t };
-						const Pose cp = { c_x[c], c_y[c], c_t[c] };
-						if (identical_poses(fp, cp) && fn.totalCost > c_total[c]) {
-							nodes[st - 1].dead = 1;
-							push = true;
-						}
+			// ---- insertion in child order, wave-uniform (a_star.h:391-402 + hybrid_a_star.h:199-205);
+			// every per-child value is read from its lane's registers (v_readlane), not from memory
+			const unsigned long long totalBits = (unsigned long long)__double_as_longlong(total);
+			for (int c = 0; c < cnt; c++) {
+				if (!lane_read(ok ? 1u : 0u, c))
+					continue;
+				const uint32_t ckey = lane_read(key, c);
+				uint32_t cst = lane_read(st, c);
+				if (lane_read(dup ? 1u : 0u, c)) {
+					wave_vmem_sync(); // lane 0's key-map writes of this batch
+					cst = keymap[ckey];
+				}
+				const double ctotal = __longlong_as_double((long long)lane_read64(totalBits, c));
+				bool push = false;
+				if (cst == 0u) {
+					push = true; // !inFrontier && !inExplored
+				} else if (cst != kExplored) {
+					// in the open list: replace only if the poses are identical and the new path is strictly cheaper
+					const int fi = (int)cst - 1;
+					const unsigned long long hitf = __ballot(myNode == fi);
+					Pose fp;
+					double ftotal;
+					if (hitf) {
+						const int fs = __ffsll((long long)hitf) - 1;
+						fp = { c_x[fs], c_y[fs], c_t[fs] };
+						ftotal = c_total[fs];
+					} else {
+						wave_vmem_sync();
+						const Node fn = nodes[fi];
+						fp = { fn.x, fn.y, fn.t };
+						ftotal = fn.totalCost;
 					}
-					if (push) {
-						if (nn >= maxNodes) {
-							s_status = -4;
-							break;
-						}
-						const int idx = nn++;
-						c_node[c] = idx;
-						keymap[ckey] = (uint32_t)idx + 1u;
-						HeapEntry e;
-						e.ckey = cost_key(c_total[c]);
-						e.nseq = 0xFFFFFFFFu - seq;
-						seq++;
-						e.node = (uint32_t)idx;
-						heap_push(heap, hs, e);
+					const Pose cp = { c_x[c], c_y[c], c_t[c] };
+					if (identical_poses(fp, cp) && ftotal > ctotal) {
+						if (lane == 0)
+							nodes[fi].dead = 1;
+						if (myNode == fi)
+							myNode = -1; // its staged copy must not be used any more
+						push = true;
 					}
 				}
-				s_heapSize = hs;
-				s_nNodes = nn;
-				s_seq = seq;
+				if (push) {
+					if (nNodes >= maxNodes) {
+						capacity = true;
+						break;
+					}
+					const int idx = nNodes++;
+					if (lane == c)
+						myNode = idx;
+					if (lane == 0)
+						keymap[ckey] = (uint32_t)idx + 1u;
+					HeapEntry e;
+					e.ckey = cost_key(ctotal);
+					e.nseq = 0xFFFFFFFFu - seq;
+					seq++;
+					e.node = (uint32_t)idx;
+					HeapEntry sp;
+					if (front_insert(front, frontCount, e, lane, sp))
+						spill(sp);
+				}
 			}
-			__syncthreads();
 			PP_STAMP(PH_INSERT);
 			// ---- every lane writes the node record of its own child
-			if (c_node[lane] >= 0) {
+			if (myNode >= 0) {
 				Node nd;
-				nd.x = c_x[lane];
-				nd.y = c_y[lane];
-				nd.t = c_t[lane];
-				nd.pathCost = c_cost[lane];
-				nd.totalCost = c_total[lane];
-				nd.length = c_len[lane];
+				nd.x = child.x;
+				nd.y = child.y;
+				nd.t = child.t;
+				nd.pathCost = gcost;
+				nd.totalCost = total;
+				nd.length = len;
+				nd.h = hh;
+				nd.sinT = cs;
+				nd.cosT = cc;
 				nd.parent = ni;
-				nd.key = c_key[lane];
-				nd.action = (int16_t)(base + lane);
+				nd.key = key;
+				nd.action = (int16_t)p;
 				nd.dead = 0;
-				nodes[c_node[lane]] = nd;
+				nodes[myNode] = nd;
 			}
-			__syncthreads();
 			PP_STAMP(PH_WRITE);
-			if (s_status == -4) {
-				capacity = true;
+			if (capacity)
 				break;
-			}
 		}
 		if (capacity) {
 			status = -4;
@@ -381,7 +538,15 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 		if (tryRs) {
 			nRsAttempts++;
 			// GetOptimalPath (reeds_shepp.cpp:654-683): lane w evaluates word w
-			Pose rel = rs::between(goal, ppose);
+			Pose rel;
+			{
+				// goal - start (geometry/2dplane.h:65-79) with the stored sin/cos of the node's heading
+				const double dx = goal.x - ppose.x, dy = goal.y - ppose.y;
+				const double s = -pSin, c = pCos;
+				rel.x = c * dx + (-s) * dy;
+				rel.y = s * dx + c * dy;
+				rel.t = wrap_theta(wrap_theta(goal.t - ppose.t));
+			}
 			rel.x = rel.x / A.rmin;
 			rel.y = rel.y / A.rmin;
 			float wcost = __builtin_huge_valf();
@@ -417,8 +582,8 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 					float lastRatio;
 					int checks = 0;
 					const bool valid = is_path_valid(m, path, path.init, lastRatio, checks);
-					c_valid[0] = 0;
-					c_state[0] = (uint32_t)checks;
+					c_valid[kRsSlot] = 0;
+					s_rsChecks = checks;
 					if (valid) {
 						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
 						const Pose child = path.interpolate(1.0);
@@ -428,79 +593,106 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 						const double cost = pathAndSwitchingCosts + voro;
 						uint32_t key;
 						if (A.ks.pack(ix, iy, it, key)) {
-							const double childPathCost = parent.pathCost + cost;
-							const double total = childPathCost + combined_heuristic(A.heur, m, field, goal, child);
-							const uint32_t st = keymap[key];
-							bool push = false;
-							if (st == 0u)
-								push = true;
-							else if (st != kExplored) {
-								const Node fn = nodes[st - 1];
-								const Pose fp = { fn.x, fn.y, fn.t };
-								if (identical_poses(fp, child) && fn.totalCost > total) {
-									nodes[st - 1].dead = 1;
-									push = true;
-								}
-							}
-							if (push) {
-								int hs = s_heapSize, nn = s_nNodes;
-								if (nn >= maxNodes) {
-									s_status = -4;
-								} else {
-									const int idx = nn++;
-									Node nd;
-									nd.x = child.x;
-									nd.y = child.y;
-									nd.t = child.t;
-									nd.pathCost = childPathCost;
-									nd.totalCost = total;
-									nd.length = path.length;
-									nd.parent = ni;
-									nd.key = key;
-									nd.action = (int16_t)(1000 + word);
-									nd.dead = 0;
-									nodes[idx] = nd;
-									keymap[key] = (uint32_t)idx + 1u;
-									HeapEntry e;
-									e.ckey = cost_key(total);
-									e.nseq = 0xFFFFFFFFu - s_seq;
-									s_seq = s_seq + 1;
-									e.node = (uint32_t)idx;
-									heap_push(heap, hs, e);
-									s_heapSize = hs;
-									s_nNodes = nn;
-									c_valid[0] = 1;
-									c_node[0] = idx;
-								}
-							}
+							double s_, c_;
+							sincos(child.t, &s_, &c_);
+							const double hh = combined_heuristic_sc(A.heur, m, field, goal, child, s_, c_);
+							c_valid[kRsSlot] = 1;
+							c_key[kRsSlot] = key;
+							c_x[kRsSlot] = child.x;
+							c_y[kRsSlot] = child.y;
+							c_t[kRsSlot] = child.t;
+							c_cost[kRsSlot] = pPathCost + cost;
+							c_total[kRsSlot] = (pPathCost + cost) + hh;
+							c_len[kRsSlot] = path.length;
+							c_h[kRsSlot] = hh;
+							c_sin[kRsSlot] = s_;
+							c_cos[kRsSlot] = c_;
+							c_state[kRsSlot] = keymap[key];
+							c_action[kRsSlot] = (int16_t)(1000 + word);
 						}
 					}
 				}
-				__syncthreads();
+				wave_lds_sync();
 				rsPathChecks++;
-				rsStateChecks += (long long)c_state[0];
-				if (c_valid[0]) {
-					if (lane == 0 && nRsLog < kRsLogCap) {
-						RsLogEntry le;
-						le.node = c_node[0];
-						le.word = word;
-						le.t = bt;
-						le.u = bu;
-						le.v = bv;
-						rsLog[nRsLog] = le;
+				rsStateChecks += (long long)s_rsChecks;
+				if (c_valid[kRsSlot]) {
+					const uint32_t ckey = c_key[kRsSlot];
+					const uint32_t cst = c_state[kRsSlot];
+					bool push = false;
+					if (cst == 0u)
+						push = true;
+					else if (cst != kExplored) {
+						const int fi = (int)cst - 1;
+						const unsigned long long hitf = __ballot(myNode == fi);
+						Pose fp;
+						double ftotal;
+						if (hitf) {
+							const int fs = __ffsll((long long)hitf) - 1;
+							fp = { c_x[fs], c_y[fs], c_t[fs] };
+							ftotal = c_total[fs];
+						} else {
+							wave_vmem_sync();
+							const Node fn = nodes[fi];
+							fp = { fn.x, fn.y, fn.t };
+							ftotal = fn.totalCost;
+						}
+						const Pose cp = { c_x[kRsSlot], c_y[kRsSlot], c_t[kRsSlot] };
+						if (identical_poses(fp, cp) && ftotal > c_total[kRsSlot]) {
+							if (lane == 0)
+								nodes[fi].dead = 1;
+							if (myNode == fi)
+								myNode = -1;
+							push = true;
+						}
 					}
-					nRsLog++;
+					if (push) {
+						if (nNodes >= maxNodes) {
+							status = -4;
+							break;
+						}
+						const int idx = nNodes++;
+						if (lane == 0) {
+							Node nd;
+							nd.x = c_x[kRsSlot];
+							nd.y = c_y[kRsSlot];
+							nd.t = c_t[kRsSlot];
+							nd.pathCost = c_cost[kRsSlot];
+							nd.totalCost = c_total[kRsSlot];
+							nd.length = c_len[kRsSlot];
+							nd.h = c_h[kRsSlot];
+							nd.sinT = c_sin[kRsSlot];
+							nd.cosT = c_cos[kRsSlot];
+							nd.parent = ni;
+							nd.key = ckey;
+							nd.action = c_action[kRsSlot];
+							nd.dead = 0;
+							nodes[idx] = nd;
+							keymap[ckey] = (uint32_t)idx + 1u;
+							if (nRsLog < kRsLogCap) {
+								RsLogEntry le;
+								le.node = idx;
+								le.word = word;
+								le.t = bt;
+								le.u = bu;
+								le.v = bv;
+								rsLog[nRsLog] = le;
+							}
+						}
+						rsNode = idx;
+						nRsLog++;
+						HeapEntry e;
+						e.ckey = cost_key(c_total[kRsSlot]);
+						e.nseq = 0xFFFFFFFFu - seq;
+						seq++;
+						e.node = (uint32_t)idx;
+						HeapEntry sp;
+						if (front_insert(front, frontCount, e, lane, sp))
+							spill(sp);
+					}
 				}
-				__syncthreads();
-				if (s_status == -4) {
-					status = -4;
-					break;
-				}
+				wave_lds_sync();
 			}
 		}
-		heapSize = s_heapSize;
-		nNodes = s_nNodes;
-		__syncthreads();
 		PP_STAMP(PH_RS);
 	}
 	if (kProfile && lane == 0)
@@ -515,11 +707,12 @@ __global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries
 	}
 	const long long nStateChecks = laneStateChecks + rsStateChecks;
 	const long long pathChecks = lanePathChecks + rsPathChecks;
+	__syncthreads();
 	if (lane == 0) {
 		DevResult r;
 		r.r.status = status;
 		r.r.n_expanded = nExpanded;
-		r.r.n_nodes = s_nNodes;
+		r.r.n_nodes = nNodes;
 		r.r.n_path = 0;
 		if (status == 0) {
 			int depth = 0;

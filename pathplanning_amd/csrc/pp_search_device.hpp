@@ -57,6 +57,28 @@ PPD_INLINE double nonholo_heuristic(const HeurView& h, const Pose& goal, const P
 	return nonholo_lookup(h, i, j, k);
 }
 
+/// Same as nonholo_heuristic with sin/cos of state.t supplied by the caller (they were computed when
+/// the pose was produced): between(goal, state) rotates by -state.t, whose sine is -sinS and cosine cosS.
+PPD_INLINE double nonholo_heuristic_sc(const HeurView& h, const Pose& goal, const Pose& state, double sinS, double cosS)
+{
+	const double dx = goal.x - state.x, dy = goal.y - state.y;
+	const double s = -sinS, c = cosS;
+	Pose delta;
+	delta.x = c * dx + (-s) * dy;
+	delta.y = s * dx + c * dy;
+	delta.t = wrap_theta(wrap_theta(goal.t - state.t));
+	int i = trunc_to_int(round((delta.x + h.offX) / h.spatialRes));
+	int j = trunc_to_int(round((delta.y + h.offY) / h.spatialRes));
+	int k = trunc_to_int(round(delta.t / h.angularRes));
+	if (k == h.na)
+		k = 0;
+	if (i < 0 || i >= h.nx || j < 0 || j >= h.ny) {
+		double euclideanDistance = sqrt(delta.x * delta.x + delta.y * delta.y);
+		return h.minMult * euclideanDistance;
+	}
+	return nonholo_lookup(h, i, j, k);
+}
+
 /// ObstaclesHeuristic::GetHeuristicValue, algo/heuristics.cpp:155-165.  `field` is the
 /// wavefront result of this query's goal; +inf marks cells the reference leaves unexplored.
 PPD_INLINE double obstacle_heuristic(const HeurView& h, const MapView& m, const float* field, const Pose& goal, const Pose& state)
@@ -85,12 +107,69 @@ PPD_INLINE double combined_heuristic(const HeurView& h, const MapView& m, const 
 	return value;
 }
 
+PPD_INLINE double combined_heuristic_sc(const HeurView& h, const MapView& m, const float* field, const Pose& goal, const Pose& state, double sinS, double cosS)
+{
+	double value = -__builtin_huge_val();
+	const double a = nonholo_heuristic_sc(h, goal, state, sinS, cosS);
+	value = value < a ? a : value;
+	const double b = obstacle_heuristic(h, m, field, goal, state);
+	value = value < b ? b : value;
+	return value;
+}
+
 /// HybridAStar::GraphSearch::IdenticalPoses, algo/hybrid_a_star.h:208-211
 PPD_INLINE bool identical_poses(const Pose& a, const Pose& b)
 {
 	const double tol = 1e-3;
 	const double dx = a.x - b.x, dy = a.y - b.y;
 	return sqrt(dx * dx + dy * dy) < tol && fabs(a.t - b.t) < tol * kPi / 180.0;
+}
+
+// ------------------------------------------------------ cross-lane helpers --
+// A __shfl is a ds_bpermute: an LDS round trip (~100+ cycles) that a single latency-bound wave
+// cannot hide.  These use the gfx9 data-parallel primitives (DPP) and v_readlane instead.
+PPD_INLINE unsigned int lane_read(unsigned int v, int l) { return (unsigned int)__builtin_amdgcn_readlane((int)v, l); } // l wave-uniform
+PPD_INLINE unsigned long long lane_read64(unsigned long long v, int l)
+{
+	return ((unsigned long long)lane_read((unsigned int)(v >> 32), l) << 32) | lane_read((unsigned int)v, l);
+}
+/// lane i receives lane i-1's value; lane 0 receives `fill`  (DPP wave_shr:1)
+PPD_INLINE unsigned int wave_shr1(unsigned int v, unsigned int fill) { return (unsigned int)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false); }
+/// lane i receives lane i+1's value; lane 63 receives `fill`  (DPP wave_shl:1)
+PPD_INLINE unsigned int wave_shl1(unsigned int v, unsigned int fill) { return (unsigned int)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false); }
+PPD_INLINE unsigned long long wave_shr1_64(unsigned long long v, unsigned long long fill)
+{
+	return ((unsigned long long)wave_shr1((unsigned int)(v >> 32), (unsigned int)(fill >> 32)) << 32) | wave_shr1((unsigned int)v, (unsigned int)fill);
+}
+PPD_INLINE unsigned long long wave_shl1_64(unsigned long long v, unsigned long long fill)
+{
+	return ((unsigned long long)wave_shl1((unsigned int)(v >> 32), (unsigned int)(fill >> 32)) << 32) | wave_shl1((unsigned int)v, (unsigned int)fill);
+}
+/// minimum over the 64 lanes, wave-uniform result: row_shr 1,2,4,8 then row_bcast 15 / 31 (lane 63 ends up with the total)
+PPD_INLINE unsigned int wave_min_u32(unsigned int v)
+{
+	const int id = (int)0xFFFFFFFF;
+	unsigned int x = v;
+	x = min(x, (unsigned int)__builtin_amdgcn_update_dpp(id, (int)x, 0x111, 0xF, 0xF, false));
+	x = min(x, (unsigned int)__builtin_amdgcn_update_dpp(id, (int)x, 0x112, 0xF, 0xF, false));
+	x = min(x, (unsigned int)__builtin_amdgcn_update_dpp(id, (int)x, 0x114, 0xF, 0xF, false));
+	x = min(x, (unsigned int)__builtin_amdgcn_update_dpp(id, (int)x, 0x118, 0xF, 0xF, false));
+	x = min(x, (unsigned int)__builtin_amdgcn_update_dpp(id, (int)x, 0x142, 0xA, 0xF, false));
+	x = min(x, (unsigned int)__builtin_amdgcn_update_dpp(id, (int)x, 0x143, 0xC, 0xF, false));
+	return lane_read(x, 63);
+}
+/// lane of the lexicographically smallest (k, s) over the wave (lowest lane among equals); also returns that key
+PPD_INLINE int wave_argmin_key(unsigned long long k, unsigned int s, unsigned long long& mk, unsigned int& ms)
+{
+	const unsigned int hi = (unsigned int)(k >> 32), lo = (unsigned int)k;
+	const unsigned int mhi = wave_min_u32(hi);
+	bool cand = hi == mhi;
+	const unsigned int mlo = wave_min_u32(cand ? lo : 0xFFFFFFFFu);
+	cand = cand && lo == mlo;
+	ms = wave_min_u32(cand ? s : 0xFFFFFFFFu);
+	cand = cand && s == ms;
+	mk = ((unsigned long long)mhi << 32) | mlo;
+	return __ffsll((long long)__ballot(cand)) - 1;
 }
 
 // -------------------------------------------------------------- open list --
@@ -124,56 +203,122 @@ PPD_INLINE void heap_push(HeapEntry* heap, int& size, const HeapEntry& e)
 	heap[i] = e;
 }
 
-/// whole wave (64 lanes); `size` is wave-uniform.  Returns the popped entry.
-PPD_INLINE HeapEntry heap_pop_wave(HeapEntry* heap, int& size, int lane)
+/// whole wave (64 lanes); `size` and `cachedTop` (a register copy of heap[0]) are wave-uniform.
+/// Returns the popped entry and leaves the new root in `cachedTop`: no load of heap[0] before or after,
+/// so a pop costs one memory round trip per level below the root.
+PPD_INLINE HeapEntry heap_pop_wave(HeapEntry* heap, int& size, int lane, HeapEntry& cachedTop)
 {
-	const HeapEntry top = heap[0];
+	const HeapEntry top = cachedTop;
 	const int hs = size - 1;
 	size = hs;
-	if (hs > 0) {
-		const HeapEntry last = heap[hs];
-		int i = 0;
-		for (;;) {
-			const int first = (i << 6) + 1;
-			if (first >= hs)
-				break;
-			const int c = first + lane;
-			HeapEntry e;
-			if (c < hs)
-				e = heap[c];
-			else {
-				e.ckey = ~0ull;
-				e.nseq = ~0u;
-				e.node = 0;
-			}
-			// wave arg-min of (ckey, nseq)
-			unsigned long long mk = e.ckey;
-			unsigned int ms = e.nseq;
-#pragma unroll
-			for (int off = 32; off > 0; off >>= 1) {
-				const unsigned int lo = __shfl_xor((int)(unsigned int)mk, off, 64);
-				const unsigned int hi = __shfl_xor((int)(unsigned int)(mk >> 32), off, 64);
-				const unsigned long long ok = ((unsigned long long)hi << 32) | lo;
-				const unsigned int os = __shfl_xor((int)ms, off, 64);
-				if (ok < mk || (ok == mk && os < ms)) {
-					mk = ok;
-					ms = os;
-				}
-			}
-			HeapEntry best;
-			best.ckey = mk;
-			best.nseq = ms;
-			if (!heap_before(best, last))
-				break;
-			const unsigned long long match = __ballot(e.ckey == mk && e.nseq == ms);
-			const int minLane = __ffsll((long long)match) - 1;
-			if (lane == minLane)
-				heap[i] = e;
-			i = first + minLane;
-		}
-		if (lane == 0)
-			heap[i] = last;
+	if (hs <= 0) {
+		cachedTop.ckey = ~0ull;
+		cachedTop.nseq = ~0u;
+		cachedTop.node = 0;
+		return top;
 	}
+	const HeapEntry last = heap[hs];
+	HeapEntry newRoot = last;
+	int i = 0;
+	for (;;) {
+		const int first = (i << 6) + 1;
+		if (first >= hs)
+			break;
+		const int c = first + lane;
+		HeapEntry e;
+		if (c < hs)
+			e = heap[c];
+		else {
+			e.ckey = ~0ull;
+			e.nseq = ~0u;
+			e.node = 0;
+		}
+		unsigned long long mk;
+		unsigned int ms;
+		const int minLane = wave_argmin_key(e.ckey, e.nseq, mk, ms);
+		HeapEntry best;
+		best.ckey = mk;
+		best.nseq = ms;
+		if (!heap_before(best, last))
+			break;
+		if (lane == minLane)
+			heap[i] = e;
+		if (i == 0) {
+			best.node = lane_read(e.node, minLane);
+			newRoot = best;
+		}
+		i = first + minLane;
+	}
+	if (lane == 0)
+		heap[i] = last;
+	cachedTop = newRoot;
+	return top;
+}
+
+// ----------------------------------------------------------- front buffer --
+// The best entries of the open list live in registers, one per lane, sorted: lane l holds the
+// (l+1)-th best; lanes >= count hold the MAX sentinel.  Insert and pop are a ballot + one
+// lane shift -- no memory traffic.  Entries that fall off the end spill to the 64-ary heap in
+// HBM; a pop takes whichever of (front[0], heap[0]) comes first in the reference's pop order, so
+// the pair (front, heap) pops exactly like one Frontier.
+struct FrontLane {
+	unsigned long long ckey;
+	unsigned int nseq;
+	unsigned int node;
+};
+PPD_INLINE void front_clear(FrontLane& f)
+{
+	f.ckey = ~0ull;
+	f.nseq = ~0u;
+	f.node = 0;
+}
+PPD_INLINE bool key_before(unsigned long long ak, unsigned int as, unsigned long long bk, unsigned int bs) { return ak < bk || (ak == bk && as < bs); }
+
+/// Inserts e (wave-uniform).  Returns true when an entry left the buffer (written to `spilled`).
+PPD_INLINE bool front_insert(FrontLane& f, int& count, const HeapEntry& e, int lane, HeapEntry& spilled)
+{
+	const bool mineFirst = lane < count && key_before(f.ckey, f.nseq, e.ckey, e.nseq);
+	const int pos = __popcll(__ballot(mineFirst));
+	if (pos >= 64) {
+		spilled = e;
+		return true;
+	}
+	bool spill = false;
+	if (count == 64) {
+		spilled.ckey = lane_read64(f.ckey, 63);
+		spilled.nseq = lane_read(f.nseq, 63);
+		spilled.node = lane_read(f.node, 63);
+		spill = true;
+	}
+	const unsigned long long uk = wave_shr1_64(f.ckey, ~0ull);
+	const unsigned int us = wave_shr1(f.nseq, ~0u);
+	const unsigned int un = wave_shr1(f.node, 0u);
+	if (lane > pos) {
+		f.ckey = uk;
+		f.nseq = us;
+		f.node = un;
+	} else if (lane == pos) {
+		f.ckey = e.ckey;
+		f.nseq = e.nseq;
+		f.node = e.node;
+	}
+	if (count < 64)
+		count++;
+	return spill;
+}
+
+/// Removes and returns front[0] (count > 0, wave-uniform).
+PPD_INLINE HeapEntry front_pop(FrontLane& f, int& count, int lane)
+{
+	HeapEntry top;
+	top.ckey = lane_read64(f.ckey, 0);
+	top.nseq = lane_read(f.nseq, 0);
+	top.node = lane_read(f.node, 0);
+	// every lane takes its right neighbour's entry; lanes >= count hold the sentinel, lane 63 is refilled with it
+	f.ckey = wave_shl1_64(f.ckey, ~0ull);
+	f.nseq = wave_shl1(f.nseq, ~0u);
+	f.node = wave_shl1(f.node, 0u);
+	count--;
 	return top;
 }
 
