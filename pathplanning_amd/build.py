@@ -39,6 +39,39 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_pyplanning(force=False, verbose=True):
+    """pybind11 module `pyplanning` (reference's Python surface for the hot path), linked against libpphip.so."""
+    import sysconfig
+    import pybind11
+    build()
+    host = os.path.join(HERE, "host")
+    ext = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+    out = os.path.join(LIB_DIR, "pyplanning" + ext)
+    srcs = [os.path.join(host, "pyplanning.cpp"), os.path.join(host, "planner_hip.hpp"), os.path.join(HERE, "..", "include", "pp_hip.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(x) <= os.path.getmtime(out) for x in srcs):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+           os.path.join(host, "pyplanning.cpp"), "-o", out, "-L" + LIB_DIR, "-lpphip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
+def build_plugin_test(verbose=True):
+    """tests/cpp/test_plugin.cpp against the C++ plugin header (run on the GPU box)."""
+    build()
+    out = os.path.join(LIB_DIR, "test_plugin")
+    src = os.path.join(HERE, "..", "tests", "cpp", "test_plugin.cpp")
+    cmd = ["g++", "-O2", "-std=c++17", src, "-o", out, "-L" + LIB_DIR, "-lpphip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    print(build_pyplanning())
+    print(build_plugin_test())

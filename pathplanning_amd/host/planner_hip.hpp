@@ -1,0 +1,451 @@
+// Host-side C++ mirror of the reference's plugin surface for the hot path, over the C ABI
+// (include/pp_hip.h).  Same namespace, class and method names as lfilipozzi/PathPlanning so that
+// code written against PathPlanner<> / StateValidator<> keeps compiling:
+//   algo/path_planner.h:9-45            Status, PathPlanner<Vertex>, PathPlannerSE2Base / R2Base
+//   state_space/state_space_se2.h       StateSpaceSE2 (bounds, ValidateBounds, EnforceBounds)
+//   state_validator/state_validator.h   StateValidator<State, Dim, T>
+//   state_validator/occupancy_map.h     OccupancyMap (sizes, transforms, grids)
+//   state_validator/state_validator_occupancy_map.h   StateValidatorOccupancyMap
+//   algo/hybrid_a_star.h:27-264         HybridAStar (SearchParameters, Initialize, SearchPath, GetPath, ...)
+//   algo/rrt.h, algo/rrt_star.h         RRTR2 / RRTStarR2 (+ parameters)
+// No Eigen: Point2d / Pose2d are plain structs with the accessors the reference code uses.
+// Everything computes on the GPU; constructing any of the HIP-backed classes without a device throws.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pp_hip.h"
+
+namespace Planner {
+
+template <typename T>
+using Ref = std::shared_ptr<T>;
+template <typename T, typename... Args>
+Ref<T> makeRef(Args&&... args) { return std::make_shared<T>(std::forward<Args>(args)...); }
+
+enum Status { Success = 0, Failure = -1 }; // algo/path_planner.h:9-12
+enum class Direction { Forward, Backward, NoMotion }; // paths/path.h:16-20
+
+struct Point2d { // geometry/2dplane.h:11-14 (Eigen::Vector2d in the reference)
+	double v[2] = { 0.0, 0.0 };
+	Point2d() = default;
+	Point2d(double x, double y) { v[0] = x; v[1] = y; }
+	double& x() { return v[0]; }
+	double& y() { return v[1]; }
+	const double& x() const { return v[0]; }
+	const double& y() const { return v[1]; }
+	Point2d operator+(const Point2d& o) const { return { v[0] + o.v[0], v[1] + o.v[1] }; }
+	Point2d operator-(const Point2d& o) const { return { v[0] - o.v[0], v[1] - o.v[1] }; }
+	bool operator==(const Point2d& o) const { return v[0] == o.v[0] && v[1] == o.v[1]; }
+	bool operator!=(const Point2d& o) const { return !(*this == o); }
+	double norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1]); }
+};
+
+struct Pose2d { // geometry/2dplane.h:17-45: 3 contiguous doubles, constructors wrap theta
+	Point2d position;
+	double theta = 0.0;
+	Pose2d() = default;
+	Pose2d(const Point2d& p, double t) : position(p), theta(t) { theta = WrapTheta(); }
+	Pose2d(double x, double y, double t) : position(x, y), theta(t) { theta = WrapTheta(); }
+	double& x() { return position.x(); }
+	double& y() { return position.y(); }
+	const double& x() const { return position.x(); }
+	const double& y() const { return position.y(); }
+	double WrapTheta() const
+	{
+		double t = theta;
+		while (t > M_PI)
+			t -= 2 * M_PI;
+		while (t < -M_PI)
+			t += 2 * M_PI;
+		return t;
+	}
+	bool operator==(const Pose2d& o) const { return position == o.position && theta == o.theta; }
+	bool operator!=(const Pose2d& o) const { return !(*this == o); }
+};
+static_assert(sizeof(Pose2d) == 24, "Pose2d must be 3 contiguous doubles (the ABI's pose layout)");
+
+struct GridCellPosition { // utils/grid.h:8-22
+	int row = -1, col = -1;
+	GridCellPosition() = default;
+	GridCellPosition(int r, int c) : row(r), col(c) { }
+	bool IsValid() const { return row >= 0 && col >= 0; }
+};
+
+inline void ppCheck(int rc)
+{
+	if (rc != 0)
+		throw std::runtime_error(std::string("libpphip: ") + pp_last_error());
+}
+
+/// algo/path_planner.h:19-41
+template <typename Vertex>
+class PathPlanner {
+public:
+	PathPlanner() { }
+	virtual ~PathPlanner() = default;
+	virtual Status SearchPath() = 0;
+	virtual std::vector<Vertex> GetPath() const = 0;
+	void SetInitState(const Vertex& init) { m_init = init; }
+	void SetGoalState(const Vertex& goal) { m_goal = goal; }
+	const Vertex& GetInitState() const { return m_init; }
+	const Vertex& GetGoalState() const { return m_goal; }
+
+protected:
+	Vertex m_init;
+	Vertex m_goal;
+};
+using PathPlannerR2Base = PathPlanner<Point2d>;
+using PathPlannerSE2Base = PathPlanner<Pose2d>;
+
+/// state_space/state_space_se2.{h,cpp}
+class StateSpaceSE2 {
+public:
+	explicit StateSpaceSE2(const std::array<Pose2d, 2>& b) : bounds(b) { }
+	StateSpaceSE2(const Pose2d& lb, const Pose2d& ub) : bounds({ lb, ub }) { }
+	void EnforceBounds(Pose2d& s) const
+	{
+		s.x() = std::min(std::max(s.x(), bounds[0].x()), bounds[1].x());
+		s.y() = std::min(std::max(s.y(), bounds[0].y()), bounds[1].y());
+		s.theta = std::min(std::max(s.theta, bounds[0].theta), bounds[1].theta);
+	}
+	bool ValidateBounds(const Pose2d& s) const
+	{
+		if (s.x() < bounds[0].x() || s.x() > bounds[1].x()) return false;
+		if (s.y() < bounds[0].y() || s.y() > bounds[1].y()) return false;
+		if (s.theta < bounds[0].theta || s.theta > bounds[1].theta) return false;
+		return true;
+	}
+	const std::array<Pose2d, 2> bounds;
+};
+
+/// One GPU context shared by the objects of a process (device 0 unless PP_DEVICE is set).
+class HipContext {
+public:
+	static pp_ctx* Get()
+	{
+		static HipContext instance;
+		return instance.m_ctx;
+	}
+private:
+	HipContext()
+	{
+		int dev = 0;
+		if (const char* e = std::getenv("PP_DEVICE"))
+			dev = std::atoi(e);
+		ppCheck(pp_ctx_create(dev, nullptr, &m_ctx));
+	}
+	~HipContext() { pp_ctx_destroy(m_ctx); }
+	pp_ctx* m_ctx = nullptr;
+};
+
+/// state_validator/occupancy_map.{h,cpp}: sizes + transforms + the three grids the path reads.
+/// Map authoring (shapes, brushfire) is outside this library: the grids are set by the caller.
+class OccupancyMap {
+public:
+	explicit OccupancyMap(float res) : resolution(res) { }
+	virtual ~OccupancyMap() = default;
+	void InitializeSize(float width, float height)
+	{
+		// occupancy_map.cpp:6-14
+		m_localGridOrigin = { -width / 2.0, -height / 2.0 };
+		m_worldGridOrigin = m_localOrigin + m_localGridOrigin;
+		m_rows = (int)std::ceil(width / resolution);
+		m_columns = (int)std::ceil(height / resolution);
+		if (!(m_rows > 0 && m_columns > 0))
+			throw std::invalid_argument("Invalid grid size: received " + std::to_string(m_rows) + " x " + std::to_string(m_columns)); // utils/grid.h:69-72
+		m_occupancy.assign((size_t)m_rows * m_columns, -1);
+		m_dist2.assign((size_t)m_rows * m_columns, INT32_MAX);
+		m_pathCost.assign((size_t)m_rows * m_columns, 0.0f);
+		m_version++;
+	}
+	int Rows() const { return m_rows; }
+	int Columns() const { return m_columns; }
+	void SetPosition(const Point2d& p) { m_localOrigin = p; }
+	const Point2d& GetPosition() const { return m_localOrigin; }
+	virtual bool IsOccupied(const GridCellPosition& c) { return m_occupancy[(size_t)c.row * m_columns + c.col] >= 0; }
+	int GetOccupancyValue(int row, int col) const { return m_occupancy[(size_t)row * m_columns + col]; }
+	bool IsInsideMap(const GridCellPosition& c) const { return c.row >= 0 && c.row < m_rows && c.col >= 0 && c.col < m_columns; }
+	GridCellPosition WorldPositionToGridCell(const Point2d& p, bool bounded = true) const
+	{
+		// occupancy_map.h:106-117,175-183
+		int row = (int)((p.x() - m_worldGridOrigin.x()) / resolution);
+		int col = (int)((p.y() - m_worldGridOrigin.y()) / resolution);
+		if (!bounded || IsInsideMap({ row, col }))
+			return { row, col };
+		return { -1, -1 };
+	}
+	Point2d GridCellToWorldPosition(const GridCellPosition& c) const { return m_worldGridOrigin + Point2d(c.row * resolution, c.col * resolution); }
+	const Point2d& WorldGridOrigin() const { return m_worldGridOrigin; }
+	/// Squared obstacle distance (GVD::ObstacleDistanceMap::m_distance), occupancy ids and GVD::PathCostMap, row-major.
+	void SetGrids(const int32_t* occupancy, const int32_t* dist2, const float* pathCost)
+	{
+		const size_t n = (size_t)m_rows * m_columns;
+		if (occupancy) m_occupancy.assign(occupancy, occupancy + n);
+		if (dist2) m_dist2.assign(dist2, dist2 + n);
+		if (pathCost) m_pathCost.assign(pathCost, pathCost + n);
+		m_version++;
+	}
+	const std::vector<int32_t>& Occupancy() const { return m_occupancy; }
+	const std::vector<int32_t>& Dist2() const { return m_dist2; }
+	const std::vector<float>& PathCost() const { return m_pathCost; }
+	uint64_t Version() const { return m_version; }
+	const float resolution;
+
+protected:
+	int m_rows = -1, m_columns = -1;
+	Point2d m_localOrigin, m_localGridOrigin, m_worldGridOrigin;
+	std::vector<int32_t> m_occupancy, m_dist2;
+	std::vector<float> m_pathCost;
+	uint64_t m_version = 0;
+};
+
+/// state_validator/state_validator.h:10-43 (SE2 instantiation)
+class StateValidatorSE2Base {
+public:
+	explicit StateValidatorSE2Base(const Ref<StateSpaceSE2>& s) : m_stateSpace(s) { }
+	virtual ~StateValidatorSE2Base() = default;
+	virtual bool IsStateValid(const Pose2d& state) = 0;
+	Ref<StateSpaceSE2>& GetStateSpace() { return m_stateSpace; }
+protected:
+	Ref<StateSpaceSE2> m_stateSpace;
+};
+
+/// state_validator/state_validator_occupancy_map.{h,cpp}, GPU-backed.
+class StateValidatorOccupancyMap : public StateValidatorSE2Base {
+public:
+	StateValidatorOccupancyMap(const Ref<StateSpaceSE2>& stateSpace, const Ref<OccupancyMap>& map) : StateValidatorSE2Base(stateSpace), m_map(map)
+	{
+		// state_validator_occupancy_map.cpp:6-13: the map is sized from the state-space bounds (float)
+		float width = stateSpace->bounds[1].x() - stateSpace->bounds[0].x();
+		float height = stateSpace->bounds[1].y() - stateSpace->bounds[0].y();
+		m_map->InitializeSize(width, height);
+	}
+	~StateValidatorOccupancyMap() override
+	{
+		if (m_dev)
+			pp_map_destroy(m_dev);
+	}
+	bool IsStateValid(const Pose2d& state) override
+	{
+		uint8_t v = 0;
+		ppCheck(pp_check_states(Device(), 1, &state.position.v[0], &v));
+		return v != 0;
+	}
+	/// batched: n poses -> n flags
+	std::vector<uint8_t> IsStateValid(const std::vector<Pose2d>& states)
+	{
+		std::vector<uint8_t> out(states.size());
+		if (!states.empty())
+			ppCheck(pp_check_states(Device(), (int64_t)states.size(), &states[0].position.v[0], out.data()));
+		return out;
+	}
+	/// IsPathValid over constant-steer arcs given as (start, curvature, length, direction)
+	bool IsArcValid(const Pose2d& from, double curvature, double length, Direction dir, float* last = nullptr)
+	{
+		uint8_t v = 0;
+		float l = 0;
+		int32_t d = dir == Direction::Backward ? 1 : 0;
+		ppCheck(pp_check_arcs(Device(), 1, &from.position.v[0], &curvature, &length, &d, &v, &l));
+		if (last)
+			*last = l;
+		return v != 0;
+	}
+	Ref<OccupancyMap>& GetOccupancyMap() { return m_map; }
+	/// device map set, (re)uploaded when the host grids or the tunables changed
+	pp_map* Device()
+	{
+		if (!m_dev) {
+			pp_map_desc d {};
+			d.rows = m_map->Rows();
+			d.cols = m_map->Columns();
+			d.resolution = m_map->resolution;
+			d.grid_origin[0] = m_map->WorldGridOrigin().x();
+			d.grid_origin[1] = m_map->WorldGridOrigin().y();
+			d.local_origin[0] = m_map->GetPosition().x();
+			d.local_origin[1] = m_map->GetPosition().y();
+			const auto& b = m_stateSpace->bounds;
+			d.lower[0] = b[0].x(); d.lower[1] = b[0].y(); d.lower[2] = b[0].theta;
+			d.upper[0] = b[1].x(); d.upper[1] = b[1].y(); d.upper[2] = b[1].theta;
+			ppCheck(pp_map_create(HipContext::Get(), &d, &m_dev));
+			m_uploaded = ~0ull;
+		}
+		if (m_uploaded != m_map->Version()) {
+			ppCheck(pp_map_upload_dist2(m_dev, m_map->Dist2().data()));
+			ppCheck(pp_map_upload_occupancy(m_dev, m_map->Occupancy().data()));
+			ppCheck(pp_map_upload_path_cost(m_dev, m_map->PathCost().data()));
+			m_uploaded = m_map->Version();
+		}
+		ppCheck(pp_map_set_validator(m_dev, minSafeRadius, minPathInterpolationDistance));
+		return m_dev;
+	}
+	float minPathInterpolationDistance = 0.1f; // state_validator_occupancy_map.h:27-28
+	float minSafeRadius = 1.0f;
+
+private:
+	Ref<OccupancyMap> m_map;
+	pp_map* m_dev = nullptr;
+	uint64_t m_uploaded = ~0ull;
+};
+
+/// algo/hybrid_a_star.h:27-264 -- graph search on the GPU (post-processing / smoothing out of scope).
+class HybridAStar : public PathPlannerSE2Base {
+public:
+	struct SearchParameters { // algo/hybrid_a_star.h:29-50
+		const double wheelbase = 2.6;
+		const double minTurningRadius = 2.0;
+		const double directionSwitchingCost = 0.0;
+		const double reverseCostMultiplier = 1.0;
+		const double forwardCostMultiplier = 1.0;
+		const double voronoiCostMultiplier = 1.0;
+		const unsigned int numGeneratedMotion = 5;
+		const double spatialResolution = 1.0;
+		const double angularResolution = 0.0872;
+		SearchParameters() = default;
+		SearchParameters(double minTurningRadius, double directionSwitchingCost, double reverseCostMultiplier, double forwardCostMultiplier,
+			double voronoiCostMultiplier, unsigned int numGeneratedMotion, double spatialResolution, double angularResolution) :
+			minTurningRadius(minTurningRadius), directionSwitchingCost(directionSwitchingCost), reverseCostMultiplier(reverseCostMultiplier),
+			forwardCostMultiplier(forwardCostMultiplier), voronoiCostMultiplier(voronoiCostMultiplier), numGeneratedMotion(numGeneratedMotion),
+			spatialResolution(spatialResolution), angularResolution(angularResolution) { }
+	};
+	struct Stats {
+		Status graphSearchStatus = Status::Failure;
+	};
+
+	HybridAStar() : HybridAStar(SearchParameters()) { }
+	explicit HybridAStar(const SearchParameters& p, int maxBatch = 1, int maxNodes = 81920) : m_param(p), m_maxBatch(maxBatch), m_maxNodes(maxNodes) { }
+	~HybridAStar() override
+	{
+		if (m_planner)
+			pp_planner_destroy(m_planner);
+	}
+	/// hybrid_a_star.cpp:206-235: builds the non-holonomic table (on the device) and the per-query workspaces
+	bool Initialize(const Ref<StateValidatorOccupancyMap>& validator)
+	{
+		if (!validator || !validator->GetStateSpace())
+			return isInitialized = false;
+		m_validator = validator;
+		pp_hybrid_params hp { m_param.wheelbase, m_param.minTurningRadius, m_param.directionSwitchingCost, m_param.reverseCostMultiplier,
+			m_param.forwardCostMultiplier, m_param.voronoiCostMultiplier, m_param.numGeneratedMotion, m_param.spatialResolution, m_param.angularResolution, 1, 1 };
+		if (m_planner) {
+			pp_planner_destroy(m_planner);
+			m_planner = nullptr;
+		}
+		if (pp_planner_create(validator->Device(), &hp, m_maxBatch, m_maxNodes, &m_planner))
+			return isInitialized = false;
+		if (pp_planner_set_nonholo_table(m_planner, nullptr))
+			return isInitialized = false;
+		return isInitialized = true;
+	}
+	Status SearchPath() override
+	{
+		if (!isInitialized)
+			return Status::Failure; // "The algorithm has not been initialized successfully." (hybrid_a_star.cpp:243-246)
+		m_validator->Device(); // pushes map edits / tunables
+		pp_query_result r {};
+		uint64_t seed = m_seed;
+		if (pp_planner_search_batch(m_planner, 1, &m_init.position.v[0], &m_goal.position.v[0], &seed, &r))
+			return m_stats.graphSearchStatus = Status::Failure;
+		m_last = r;
+		return m_stats.graphSearchStatus = (r.status == 0 ? Status::Success : Status::Failure);
+	}
+	/// graph-search path nodes (root .. goal)
+	std::vector<Pose2d> GetPath() const override
+	{
+		std::vector<Pose2d> out((size_t)m_last.n_path);
+		if (m_last.n_path > 0)
+			ppCheck(pp_planner_get_path(m_planner, 0, &out[0].position.v[0], nullptr, nullptr, nullptr, nullptr));
+		return out;
+	}
+	double GetGraphSearchOptimalCost() const { return m_last.status == 0 ? m_last.cost : INFINITY; }
+	const Stats& GetStats() const { return m_stats; }
+	const SearchParameters& GetSearchParameters() const { return m_param; }
+	Ref<StateValidatorOccupancyMap>& GetStateValidator() { return m_validator; }
+	/// the reference's process-global RNG becomes one stream per query
+	void SetSeed(uint64_t seed) { m_seed = seed; }
+	/// batch of independent queries (n <= maxBatch)
+	std::vector<pp_query_result> SearchBatch(const std::vector<Pose2d>& starts, const std::vector<Pose2d>& goals, const std::vector<uint64_t>& seeds)
+	{
+		if (!isInitialized || starts.size() != goals.size() || starts.size() != seeds.size())
+			throw std::invalid_argument("HybridAStar::SearchBatch: not initialised or size mismatch");
+		m_validator->Device();
+		std::vector<pp_query_result> res(starts.size());
+		if (!starts.empty())
+			ppCheck(pp_planner_search_batch(m_planner, (int32_t)starts.size(), &starts[0].position.v[0], &goals[0].position.v[0], seeds.data(), res.data()));
+		return res;
+	}
+	std::vector<Pose2d> GetPathOf(int q, int nPath) const
+	{
+		std::vector<Pose2d> out((size_t)nPath);
+		if (nPath > 0)
+			ppCheck(pp_planner_get_path(m_planner, q, &out[0].position.v[0], nullptr, nullptr, nullptr, nullptr));
+		return out;
+	}
+	float pathInterpolation = 0.1f; // kept for source compatibility (post-processing is not in this library)
+
+private:
+	SearchParameters m_param;
+	int m_maxBatch, m_maxNodes;
+	bool isInitialized = false;
+	Ref<StateValidatorOccupancyMap> m_validator;
+	pp_planner* m_planner = nullptr;
+	pp_query_result m_last {};
+	Stats m_stats;
+	uint64_t m_seed = 0;
+};
+
+/// algo/rrt.h:12-21 / algo/rrt_star.h:12-21
+struct RRTParameters {
+	unsigned int maxIteration = 100;
+	unsigned int maxNumberTreeNode = 1e4;
+	double maxConnectionDistance = 0.1;
+	double goalBias = 0.05;
+};
+struct RRTStarParameters {
+	unsigned int maxIteration = 1e4;
+	unsigned int maxNumberTreeNode = 1e4;
+	double maxConnectionDistance = 0.1;
+	double goalBias = 0.05;
+};
+
+/// RRT<Point2d, 2> / RRTStar<Point2d, 2> with PathConnectionR2; validator == nullptr is StateValidatorFree.
+template <bool kStar, typename Params>
+class RRTR2Hip : public PathPlannerR2Base {
+public:
+	RRTR2Hip(const Point2d& lower, const Point2d& upper, const Ref<StateValidatorOccupancyMap>& validator = nullptr) : m_lb(lower), m_ub(upper), m_validator(validator) { }
+	Params GetParameters() const { return m_parameters; }
+	void SetParameters(const Params& p) { m_parameters = p; }
+	void SetSeed(uint64_t s) { m_seed = s; }
+	Status SearchPath() override
+	{
+		const double params[4] = { (double)m_parameters.maxIteration, (double)m_parameters.maxNumberTreeNode, m_parameters.maxConnectionDistance, m_parameters.goalBias };
+		pp_rrt* h = nullptr;
+		pp_rrt_result r {};
+		ppCheck(pp_rrt_run(HipContext::Get(), m_validator ? m_validator->Device() : nullptr, m_lb.v, m_ub.v, params, m_init.v, m_goal.v, m_seed, kStar ? 1 : 0, &h, &r));
+		m_path.assign((size_t)r.n_path, Point2d());
+		if (r.n_path)
+			ppCheck(pp_rrt_get(h, nullptr, nullptr, nullptr, &m_path[0].v[0]));
+		pp_rrt_destroy(h);
+		m_result = r;
+		return r.status == 0 ? Status::Success : Status::Failure;
+	}
+	std::vector<Point2d> GetPath() const override { return m_path; }
+	const pp_rrt_result& GetResult() const { return m_result; }
+private:
+	Point2d m_lb, m_ub;
+	Ref<StateValidatorOccupancyMap> m_validator;
+	Params m_parameters;
+	std::vector<Point2d> m_path;
+	pp_rrt_result m_result {};
+	uint64_t m_seed = 0;
+};
+using RRTR2 = RRTR2Hip<false, RRTParameters>;
+using RRTStarR2 = RRTR2Hip<true, RRTStarParameters>;
+
+} // namespace Planner

@@ -1,0 +1,188 @@
+// pybind11 module `pyplanning`: the reference's Python surface (interfaces/python/src/pyplanning.cpp)
+// for the hot path, same class / method names, backed by libpphip.so through planner_hip.hpp.
+// Bound here: initialize, Status, Point2d, Pose2d, GridCellPosition, Direction, StateSpaceSE2,
+// OccupancyMap (+ set_grids), StateValidatorSE2Base, StateValidatorOccupancyMap, HybridAStarSearchParameters,
+// HybridAStarStats, PathPlannerSE2Base, HybridAStar; new surface: search_batch, RRT / RRTStar (the reference
+// does not bind RRT).  Map authoring classes (shapes, ObstacleListOccupancyMap, GVD) and paths are not part
+// of the hot path and are not bound.
+#include <pybind11/numpy.h>
+#include <pybind11/operators.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "planner_hip.hpp"
+
+namespace py = pybind11;
+using namespace Planner;
+
+PYBIND11_MODULE(pyplanning, m)
+{
+	m.def("initialize", []() {}); // PP_INIT: logging / profiler singletons of the reference; nothing to set up here
+
+	py::enum_<Status>(m, "Status").value("SUCCESS", Status::Success).value("FAILURE", Status::Failure);
+	py::enum_<Direction>(m, "Direction").value("FORWARD", Direction::Forward).value("BACKWARD", Direction::Backward).value("NO_MOTION", Direction::NoMotion);
+
+	py::class_<Point2d>(m, "Point2d")
+		.def(py::init<double, double>())
+		.def("x", [](Point2d& p) { return p.x(); })
+		.def("y", [](Point2d& p) { return p.y(); })
+		.def(py::self + py::self)
+		.def(py::self - py::self)
+		.def(py::self == py::self)
+		.def(py::self != py::self);
+
+	py::class_<Pose2d>(m, "Pose2d")
+		.def(py::init<const Point2d&, double>())
+		.def(py::init<double, double, double>())
+		.def_readwrite("position", &Pose2d::position)
+		.def_readwrite("theta", &Pose2d::theta)
+		.def("x", [](Pose2d& p) { return p.x(); })
+		.def("y", [](Pose2d& p) { return p.y(); })
+		.def(py::self == py::self)
+		.def(py::self != py::self);
+
+	py::class_<GridCellPosition>(m, "GridCellPosition")
+		.def(py::init<>())
+		.def(py::init<int, int>())
+		.def_readwrite("row", &GridCellPosition::row)
+		.def_readwrite("col", &GridCellPosition::col)
+		.def("__repr__", [](const GridCellPosition& c) { return "<GridCellPosition: row " + std::to_string(c.row) + ", col: " + std::to_string(c.col) + ">"; });
+
+	py::class_<StateSpaceSE2, Ref<StateSpaceSE2>>(m, "StateSpaceSE2")
+		.def(py::init<const std::array<Pose2d, 2>&>())
+		.def(py::init<const Pose2d&, const Pose2d&>())
+		.def("enforce_bounds", &StateSpaceSE2::EnforceBounds)
+		.def("validate_bounds", &StateSpaceSE2::ValidateBounds)
+		.def_readonly("bounds", &StateSpaceSE2::bounds);
+
+	py::class_<OccupancyMap, Ref<OccupancyMap>>(m, "OccupancyMap")
+		.def(py::init<float>())
+		.def("initialize_size", &OccupancyMap::InitializeSize)
+		.def("rows", &OccupancyMap::Rows)
+		.def("columns", &OccupancyMap::Columns)
+		.def("set_position", &OccupancyMap::SetPosition)
+		.def("get_position", &OccupancyMap::GetPosition)
+		.def("is_occupied", &OccupancyMap::IsOccupied)
+		.def("get_occupancy_value", &OccupancyMap::GetOccupancyValue)
+		.def("world_position_to_grid_cell", &OccupancyMap::WorldPositionToGridCell, py::arg("position"), py::arg("bounded") = true)
+		.def("grid_cell_to_world_position", &OccupancyMap::GridCellToWorldPosition)
+		.def("is_inside_map", &OccupancyMap::IsInsideMap)
+		.def("set_grids",
+			[](OccupancyMap& map, py::array_t<int32_t, py::array::c_style | py::array::forcecast> occ, py::array_t<int32_t, py::array::c_style | py::array::forcecast> d2,
+				py::array_t<float, py::array::c_style | py::array::forcecast> pc) {
+				const size_t n = (size_t)map.Rows() * map.Columns();
+				if ((size_t)occ.size() != n || (size_t)d2.size() != n || (size_t)pc.size() != n)
+					throw std::invalid_argument("set_grids: arrays must be rows x columns");
+				map.SetGrids(occ.data(), d2.data(), pc.data());
+			},
+			py::arg("occupancy"), py::arg("dist2"), py::arg("path_cost"));
+
+	py::class_<StateValidatorSE2Base, Ref<StateValidatorSE2Base>>(m, "StateValidatorSE2Base")
+		.def("is_state_valid", &StateValidatorSE2Base::IsStateValid)
+		.def_property("state_space", &StateValidatorSE2Base::GetStateSpace, nullptr);
+
+	py::class_<StateValidatorOccupancyMap, Ref<StateValidatorOccupancyMap>, StateValidatorSE2Base>(m, "StateValidatorOccupancyMap")
+		.def(py::init<const Ref<StateSpaceSE2>&, const Ref<OccupancyMap>&>())
+		.def("get_occupancy_map", &StateValidatorOccupancyMap::GetOccupancyMap)
+		.def("is_state_valid", py::overload_cast<const Pose2d&>(&StateValidatorOccupancyMap::IsStateValid))
+		.def("is_states_valid",
+			[](StateValidatorOccupancyMap& v, py::array_t<double, py::array::c_style | py::array::forcecast> poses) {
+				if (poses.ndim() != 2 || poses.shape(1) != 3)
+					throw std::invalid_argument("poses must be (n, 3)");
+				py::array_t<uint8_t> out(poses.shape(0));
+				if (poses.shape(0))
+					ppCheck(pp_check_states(v.Device(), poses.shape(0), poses.data(), out.mutable_data()));
+				return out;
+			})
+		.def("is_arc_valid",
+			[](StateValidatorOccupancyMap& v, const Pose2d& from, double curvature, double length, Direction dir) {
+				float last = 0;
+				bool ok = v.IsArcValid(from, curvature, length, dir, &last);
+				return py::make_tuple(ok, last);
+			})
+		.def_readwrite("min_path_interpolation_distance", &StateValidatorOccupancyMap::minPathInterpolationDistance)
+		.def_readwrite("min_safe_radius", &StateValidatorOccupancyMap::minSafeRadius);
+
+	struct PathPlannerSE2BaseWrapper : PathPlannerSE2Base {
+		using PathPlannerSE2Base::PathPlannerSE2Base;
+		Status SearchPath() override { PYBIND11_OVERRIDE_PURE(Status, PathPlannerSE2Base, SearchPath); }
+		std::vector<Pose2d> GetPath() const override { PYBIND11_OVERRIDE_PURE(std::vector<Pose2d>, PathPlannerSE2Base, GetPath); }
+	};
+	py::class_<PathPlannerSE2Base, PathPlannerSE2BaseWrapper>(m, "PathPlannerSE2Base")
+		.def(py::init<>())
+		.def("search_path", &PathPlannerSE2Base::SearchPath)
+		.def("get_path", &PathPlannerSE2Base::GetPath)
+		.def("set_init_state", &PathPlannerSE2Base::SetInitState)
+		.def("set_goal_state", &PathPlannerSE2Base::SetGoalState);
+
+	py::class_<HybridAStar::SearchParameters>(m, "HybridAStarSearchParameters")
+		.def(py::init<>())
+		.def(py::init<double, double, double, double, double, unsigned int, double, double>())
+		.def_readonly("wheelbase", &HybridAStar::SearchParameters::wheelbase)
+		.def_readonly("min_turning_radius", &HybridAStar::SearchParameters::minTurningRadius)
+		.def_readonly("direction_switching_cost", &HybridAStar::SearchParameters::directionSwitchingCost)
+		.def_readonly("reverse_cost_multiplier", &HybridAStar::SearchParameters::reverseCostMultiplier)
+		.def_readonly("forward_cost_multiplier", &HybridAStar::SearchParameters::forwardCostMultiplier)
+		.def_readonly("voronoi_cost_multiplier", &HybridAStar::SearchParameters::voronoiCostMultiplier)
+		.def_readonly("num_generated_motion", &HybridAStar::SearchParameters::numGeneratedMotion)
+		.def_readonly("spatial_resolution", &HybridAStar::SearchParameters::spatialResolution)
+		.def_readonly("angular_resolution", &HybridAStar::SearchParameters::angularResolution);
+
+	py::class_<HybridAStar::Stats>(m, "HybridAStarStats").def_readonly("graph_search_status", &HybridAStar::Stats::graphSearchStatus);
+
+	py::class_<HybridAStar, PathPlannerSE2Base>(m, "HybridAStar")
+		.def(py::init<>())
+		.def(py::init<const HybridAStar::SearchParameters&>())
+		.def(py::init<const HybridAStar::SearchParameters&, int, int>(), py::arg("parameters"), py::arg("max_batch"), py::arg("max_nodes") = 81920)
+		.def("initialize", &HybridAStar::Initialize)
+		.def_readwrite("path_interpolation", &HybridAStar::pathInterpolation)
+		.def("get_stats", &HybridAStar::GetStats)
+		.def("get_graph_search_optimal_cost", &HybridAStar::GetGraphSearchOptimalCost)
+		.def("get_search_parameters", &HybridAStar::GetSearchParameters)
+		.def("set_seed", &HybridAStar::SetSeed)
+		.def("search_batch",
+			[](HybridAStar& h, py::array_t<double, py::array::c_style | py::array::forcecast> starts, py::array_t<double, py::array::c_style | py::array::forcecast> goals,
+				py::array_t<uint64_t, py::array::c_style | py::array::forcecast> seeds) {
+				const size_t n = starts.shape(0);
+				std::vector<Pose2d> s(n), g(n);
+				std::vector<uint64_t> sd(seeds.data(), seeds.data() + n);
+				for (size_t i = 0; i < n; i++) {
+					s[i] = Pose2d(starts.at(i, 0), starts.at(i, 1), starts.at(i, 2));
+					g[i] = Pose2d(goals.at(i, 0), goals.at(i, 1), goals.at(i, 2));
+				}
+				auto res = h.SearchBatch(s, g, sd);
+				py::list out;
+				for (size_t i = 0; i < n; i++)
+					out.append(py::make_tuple(res[i].status, res[i].cost, res[i].n_expanded, res[i].n_path));
+				return out;
+			});
+
+	py::class_<RRTParameters>(m, "RRTParameters")
+		.def(py::init<>())
+		.def_readwrite("max_iteration", &RRTParameters::maxIteration)
+		.def_readwrite("max_number_tree_node", &RRTParameters::maxNumberTreeNode)
+		.def_readwrite("max_connection_distance", &RRTParameters::maxConnectionDistance)
+		.def_readwrite("goal_bias", &RRTParameters::goalBias);
+	py::class_<RRTStarParameters>(m, "RRTStarParameters")
+		.def(py::init<>())
+		.def_readwrite("max_iteration", &RRTStarParameters::maxIteration)
+		.def_readwrite("max_number_tree_node", &RRTStarParameters::maxNumberTreeNode)
+		.def_readwrite("max_connection_distance", &RRTStarParameters::maxConnectionDistance)
+		.def_readwrite("goal_bias", &RRTStarParameters::goalBias);
+	py::class_<RRTR2>(m, "RRTR2")
+		.def(py::init<const Point2d&, const Point2d&, const Ref<StateValidatorOccupancyMap>&>(), py::arg("lower"), py::arg("upper"), py::arg("validator") = nullptr)
+		.def("set_parameters", &RRTR2::SetParameters)
+		.def("set_seed", &RRTR2::SetSeed)
+		.def("set_init_state", &RRTR2::SetInitState)
+		.def("set_goal_state", &RRTR2::SetGoalState)
+		.def("search_path", &RRTR2::SearchPath)
+		.def("get_path", &RRTR2::GetPath);
+	py::class_<RRTStarR2>(m, "RRTStarR2")
+		.def(py::init<const Point2d&, const Point2d&, const Ref<StateValidatorOccupancyMap>&>(), py::arg("lower"), py::arg("upper"), py::arg("validator") = nullptr)
+		.def("set_parameters", &RRTStarR2::SetParameters)
+		.def("set_seed", &RRTStarR2::SetSeed)
+		.def("set_init_state", &RRTStarR2::SetInitState)
+		.def("set_goal_state", &RRTStarR2::SetGoalState)
+		.def("search_path", &RRTStarR2::SearchPath)
+		.def("get_path", &RRTStarR2::GetPath);
+}
