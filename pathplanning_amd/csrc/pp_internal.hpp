@@ -65,7 +65,7 @@ struct WavefrontWorkspace;
 int64_t wavefront_workspace_bytes(int rows, int cols);
 /// Runs nGoals wavefronts; goalCells[g] = row*cols+col or -1 (goal outside the map -> field stays +inf).
 hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
-	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev);
+	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev = nullptr);
 
 } // namespace pph
 

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the exact-order wavefront kernel (stamped diagnostic build)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pathplanning_amd as pa  # noqa: E402
+from pathplanning_amd import synthetic  # noqa: E402
+from pathplanning_amd._lib import check, ptr  # noqa: E402
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 768
+ctx = pa.Context(0)
+m = synthetic.make_map(1024, 24, seed=1)
+ms, val = synthetic.upload(ctx, m)
+goals = synthetic.sample_valid_poses(val, m, G, seed=2000)[:, :2].copy()
+cnt = np.zeros((G, 10), dtype=np.uint64)
+for it in range(2):
+    ctx.timer_start()
+    check(ctx.lib.pp_obstacle_heuristic_profile(ms.h, G, ptr(np.ascontiguousarray(goals)), ptr(cnt)))
+    ms_ = ctx.timer_stop()
+names = ["init", "min", "partition", "sort", "offer", "push", "tail"]
+c = cnt.astype(np.float64)
+tot = c[:, :7].sum()
+print("goals %d  wall %.1f ms (incl. alloc/copies)" % (G, ms_))
+print("rounds/goal %.0f  mean window %.0f  mean padded sort size %.0f" % (c[:, 7].mean(), c[:, 8].sum() / c[:, 7].sum(), c[:, 9].sum() / c[:, 7].sum()))
+for i, nm in enumerate(names):
+    print("  %-9s %5.1f %%  %.0f cycles/round" % (nm, 100 * c[:, i].sum() / tot, c[:, i].sum() / c[:, 7].sum()))
+print("cycles/goal %.3g" % (c[:, :7].sum(1).mean()))
