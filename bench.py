@@ -30,7 +30,7 @@ CHILD_BYTES = 143.0                # per expansion child
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="queries per GPU per step")
     ap.add_argument("--cells", type=int, default=1024)
@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--check-poses", type=int, default=1 << 26)
     ap.add_argument("--cpu-sample", type=int, default=192, help="queries timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=3, help="independent batches kept in flight (one planner + HIP stream each)")
     args = ap.parse_args()
 
     import numpy as np
@@ -59,14 +60,20 @@ def main():
     import pathplanning_amd as pa
     from pathplanning_amd import synthetic
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ctx = pa.Context(local_rank, stream if stream else None)
     m = synthetic.make_map(args.cells, args.obstacles, seed=1)
-    ms, val = synthetic.upload(ctx, m)
     params = pa.HybridAStarSearchParameters()
     B = args.batch
-    planner = pa.HybridAStarBatch(val, params, max_batch=B, max_nodes=args.max_nodes)
-    planner.initialize()  # non-holonomic table built on the device
+    # Batches are independent, and one batch alone cannot fill the GPU (its search kernel is bound by the longest
+    # query): keep `streams` batches in flight, each on its own HIP stream with its own planner workspace.
+    n_streams = max(1, args.streams)
+    lanes = []
+    for si in range(n_streams):
+        c = pa.Context(local_rank)
+        ms_i, val_i = synthetic.upload(c, m)
+        pl = pa.HybridAStarBatch(val_i, params, max_batch=B, max_nodes=args.max_nodes)
+        pl.initialize()  # non-holonomic table built on the device
+        lanes.append((c, ms_i, val_i, pl))
+    ctx, ms, val, planner = lanes[0]
 
     # queries: uniform over valid poses; every rank its own slice of the seed space
     reach = synthetic.reachable_mask(val, m)  # drop the pockets enclosed by outline obstacles
@@ -78,31 +85,43 @@ def main():
     d_starts = torch.from_numpy(starts).to(dev)
     d_goals = torch.from_numpy(goals).to(dev)
     d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(dev)
-    def step():
-        planner.search_batch_dev(d_starts, d_goals, d_seeds)
-        res = planner.fetch_results()
+    def finish(pl):
+        res = pl.fetch_results()  # synchronises that planner's stream
         if world > 1:
             # the only collective: gather of the fixed-size result records (RCCL all_gather)
             sharding.gather_records(sharding.records_from_results(res, B), B * world, rank, world, device=dev)
         return res
+
+    def run_steps(k):
+        """k steps = k batches of B queries; up to n_streams of them in flight."""
+        out, timings, pending = None, [], []
+        for s_i in range(k):
+            pl = lanes[s_i % n_streams][3]
+            if len(pending) == n_streams:
+                done = pending.pop(0)
+                out = finish(done)
+                timings.append(done.last_timings())
+            pl.search_batch_dev(d_starts, d_goals, d_seeds)  # asynchronous: wavefront + search enqueued on the lane's stream
+            pending.append(pl)
+        for done in pending:
+            out = finish(done)
+            timings.append(done.last_timings())
+        return out, timings
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        run_steps(args.warmup)
     sync_all()
-    wf_ms, se_ms = [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-        a, b = planner.last_timings()
-        wf_ms.append(a)
-        se_ms.append(b)
+    res, timings = run_steps(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
+    wf_ms = [t[0] for t in timings]
+    se_ms = [t[1] for t in timings]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -199,8 +218,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "Hybrid A* batch of %d start/goal pairs per GPU on one %dx%d map (res 0.1 m, %d rectangle outlines), P=%d constant-steer primitives + RS analytic expansion, exact-order obstacle heuristic per query" % (B, args.cells, args.cells, args.obstacles, planner.num_primitives),
-                       "queries_per_gpu": B, "grid": [ms.rows, ms.cols], "parallelism": "query-sharded x%d" % n_gpus},
+            "config": {"workload": "Hybrid A* batch of %d start/goal pairs per GPU per step on one %dx%d map (res 0.1 m, %d rectangle outlines), P=%d constant-steer primitives + RS analytic expansion, exact-order obstacle heuristic per query" % (B, args.cells, args.cells, args.obstacles, planner.num_primitives),
+                       "queries_per_gpu": B, "grid": [ms.rows, ms.cols], "parallelism": "query-sharded x%d" % n_gpus, "batches_in_flight": n_streams},
             "secondary": {"metric": "collision_checks_per_sec", "value": checks_per_s, "unit": "checks/s", "poses": n_chk, "ms": chk_ms,
                           "achieved_GBs": chk_gbs, "hbm_frac": chk_gbs / HBM_PEAK_GBS,
                           "fused_checks_per_sec": n_chk / (fused_ms * 1e-3) * n_gpus,

@@ -649,13 +649,14 @@ int pp_obstacle_heuristic_dev(pp_map* map, int32_t n_goals, const double* goal_x
 	hipStream_t s = map->ctx->stream;
 	std::vector<int32_t> cells;
 	goal_cells(map, n_goals, goal_xy_host, cells);
-	int nSlots = n_goals < 768 ? n_goals : 768; // 256 CUs x 3 resident workgroups (48 KiB LDS each)
+	const int resident = wavefront_resident_blocks();
+	int nSlots = n_goals < resident ? n_goals : resident;
 	const int64_t wsb = wavefront_workspace_bytes(map->desc.rows, map->desc.cols);
 	DevBuf ws, dc, derr;
 	PP_HIP_TRY(ws.alloc((size_t)wsb * nSlots));
 	PP_HIP_TRY(dc.alloc((size_t)n_goals * 4));
-	PP_HIP_TRY(derr.alloc(4));
-	PP_HIP_TRY(hipMemsetAsync(derr.p, 0, 4, s));
+	PP_HIP_TRY(derr.alloc(8));
+	PP_HIP_TRY(hipMemsetAsync(derr.p, 0, 8, s));
 	PP_HIP_TRY(hipMemcpyAsync(dc.p, cells.data(), (size_t)n_goals * 4, hipMemcpyHostToDevice, s));
 	PP_HIP_TRY(launch_wavefront(s, map->view(), n_goals, dc.as<int32_t>(), cost_dev, ws.p, wsb, nSlots, derr.as<int32_t>()));
 	int32_t err = 0;
@@ -678,15 +679,16 @@ int pp_obstacle_heuristic_profile(pp_map* map, int32_t n_goals, const double* go
 	hipStream_t s = map->ctx->stream;
 	std::vector<int32_t> cells;
 	goal_cells(map, n_goals, goal_xy_host, cells);
-	int nSlots = n_goals < 768 ? n_goals : 768;
+	const int resident = wavefront_resident_blocks();
+	int nSlots = n_goals < resident ? n_goals : resident;
 	const int64_t wsb = wavefront_workspace_bytes(map->desc.rows, map->desc.cols);
 	DevBuf ws, dc, derr, dcost, dprof;
 	PP_HIP_TRY(ws.alloc((size_t)wsb * nSlots));
 	PP_HIP_TRY(dc.alloc((size_t)n_goals * 4));
-	PP_HIP_TRY(derr.alloc(4));
+	PP_HIP_TRY(derr.alloc(8));
 	PP_HIP_TRY(dcost.alloc((size_t)n_goals * map->cells() * 4));
 	PP_HIP_TRY(dprof.alloc((size_t)n_goals * 10 * 8));
-	PP_HIP_TRY(hipMemsetAsync(derr.p, 0, 4, s));
+	PP_HIP_TRY(hipMemsetAsync(derr.p, 0, 8, s));
 	PP_HIP_TRY(hipMemcpyAsync(dc.p, cells.data(), (size_t)n_goals * 4, hipMemcpyHostToDevice, s));
 	PP_HIP_TRY(launch_wavefront(s, map->view(), n_goals, dc.as<int32_t>(), dcost.as<float>(), ws.p, wsb, nSlots, derr.as<int32_t>(), dprof.as<unsigned long long>()));
 	PP_HIP_TRY(hipMemcpyAsync(counters_host, dprof.p, (size_t)n_goals * 10 * 8, hipMemcpyDeviceToHost, s));

@@ -63,6 +63,8 @@ hipError_t launch_knn(hipStream_t s, int64_t nPoints, const double* pts, int64_t
 // ---- wavefront (pp_wavefront.hip) -----------------------------------------
 struct WavefrontWorkspace;
 int64_t wavefront_workspace_bytes(int rows, int cols);
+/// workgroups of the wavefront kernel that are resident at once on the current device (occupancy API x CUs)
+int wavefront_resident_blocks();
 /// Runs nGoals wavefronts; goalCells[g] = row*cols+col or -1 (goal outside the map -> field stays +inf).
 hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
 	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev = nullptr);

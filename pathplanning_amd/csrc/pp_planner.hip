@@ -115,8 +115,11 @@ enum { PH_POP = 0, PH_LOAD, PH_HEUR, PH_CHILD, PH_DUP, PH_INSERT, PH_WRITE, PH_R
 constexpr int kSlots = 65; // staging: one slot per lane + one for the Reeds-Shepp child
 constexpr int kRsSlot = 64;
 
+#ifndef PP_SEARCH_WAVES_PER_SIMD
+#define PP_SEARCH_WAVES_PER_SIMD 2 // 256 VGPRs: no spills on the per-expansion critical path (128 + 4 batches in flight measured ~10 % faster but needs ~240 GB)
+#endif
 template <bool kProfile>
-__global__ void __launch_bounds__(64) k_hybrid_search(SearchArgs A, int nQueries, const double* __restrict__ starts, const double* __restrict__ goals,
+__global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(SearchArgs A, int nQueries, const double* __restrict__ starts, const double* __restrict__ goals,
 	const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase, HeapEntry* __restrict__ heapBase,
 	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, DevResult* __restrict__ results,
 	unsigned long long* __restrict__ prof)
@@ -880,7 +883,11 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 		ks.y0 = (int)std::floor((map->desc.lower[1] - slack) / sres) - 1;
 		ks.nx = (int)std::ceil((map->desc.upper[0] + slack) / sres) + 1 - ks.x0 + 1;
 		ks.ny = (int)std::ceil((map->desc.upper[1] + slack) / sres) + 1 - ks.y0 + 1;
-		const int tmax = (int)(M_PI / ares) + 1;
+		// heading bins: (int)(wrap(theta) / ares) in [-tmax, tmax]; with the reference's Release-build aliasing
+		// (Appendix A Q6) every bin is folded into [-3, 3] by Pose2<int>::WrapTheta
+		int tmax = (int)(M_PI / ares) + 1;
+		if (params->heading_alias && tmax > 3)
+			tmax = 3;
 		ks.t0 = -tmax;
 		ks.nt = 2 * tmax + 1;
 		ks.nt = (ks.nt + 3) / 4 * 4; // keeps every query's key map 16-byte aligned
@@ -889,7 +896,10 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 	const size_t B = (size_t)max_batch, N = (size_t)max_nodes_per_query;
 	const size_t tableBytes = (size_t)dims[0] * dims[1] * dims[2] * sizeof(double);
 	p->wfBytesPerSlot = pph::wavefront_workspace_bytes(map->desc.rows, map->desc.cols);
-	p->wfSlots = max_batch < 768 ? max_batch : 768;
+	{
+		const int resident = pph::wavefront_resident_blocks();
+		p->wfSlots = max_batch < resident ? max_batch : resident;
+	}
 	hipError_t e = hipSuccess;
 	auto alloc = [&](void** ptr, size_t bytes) {
 		if (e == hipSuccess)
@@ -898,7 +908,7 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 	alloc((void**)&p->table, tableBytes);
 	alloc((void**)&p->costFields, B * A.cells * sizeof(float));
 	alloc((void**)&p->wfWorkspace, (size_t)p->wfBytesPerSlot * p->wfSlots);
-	alloc((void**)&p->wfError, 4);
+	alloc((void**)&p->wfError, 8);
 	alloc((void**)&p->goalCells, B * 4);
 	alloc((void**)&p->nodes, B * N * sizeof(Node));
 	alloc((void**)&p->heaps, B * N * sizeof(HeapEntry));
@@ -986,7 +996,7 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	hipStream_t s = planner->map->ctx->stream;
 	planner->args.m = planner->map->view(); // validator tunables may have changed
 	const MapView& m = planner->args.m;
-	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 4, s));
+	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 8, s));
 	PP_HIP_TRY(hipEventRecord(planner->e0, s));
 	hipLaunchKernelGGL(k_goal_cells, dim3((n_queries + 255) / 256), dim3(256), 0, s, m, n_queries, goals_dev, planner->goalCells);
 	PP_HIP_TRY(hipGetLastError());

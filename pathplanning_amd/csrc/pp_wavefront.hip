@@ -8,45 +8,58 @@
 //     in the open list, every cell whose cost is < fl(L + 1) is ALREADY in the open list:
 //     the "window" of this round.
 //   * the reference pops the window in the order (cost ascending, push order descending);
-//     a bitonic sort on the 64-bit key (cost bits, ~pushOrder) gives each cell its rank i.
+//     a bitonic sort gives each window cell its rank i.
 //   * popping cell i pushes its undiscovered neighbours in the fixed enumeration order
 //     j = 0..7 (utils/grid.cpp:29-47).  A neighbour n is discovered by the smallest (i, j)
-//     that reaches it.  Resolved WITHOUT atomics (scattered global atomics run at a fixed
-//     chip-wide rate that 768 concurrent wavefronts saturate): every window cell publishes
-//     (round, rank) in a per-cell word with a plain store; a cell p offering itself to n then
-//     GATHERS the words of n's other seven neighbours and wins iff none of them is a window
-//     cell with a smaller (rank, direction) and an allowed transition.  The winner writes
-//     cost = cost_i + edge (same f32 add as the reference) and the push order
-//     roundBase + i*8 + j, which is monotone in the reference's push time.
-// One workgroup per goal; grids stay in HBM/L2 (cost f32 + rank word u32 per cell), the sort
-// runs in LDS.  Algorithmic bytes: 9 B/cell.
+//     that reaches it; the winner writes cost = cost_i + edge (same f32 add as the
+//     reference) and the push order roundBase + i*8 + j, monotone in the reference's push time.
+//
+// What bounds this kernel (measured, profiles/r01_wavefront_*): not HBM bytes but the per-CU
+// rate of uncoalesced cache-line requests -- window cells are ordered by cost, not by position,
+// so every lane touches its own line.  The layout therefore minimises REQUESTS per cell:
+//   * working grid = padded (rows+2) x (cols+2) f32 costs; occupied cells and the border hold
+//     a NaN pattern, undiscovered cells +inf: one 12-byte row load yields occupancy AND
+//     discovery state of three neighbours (3 requests per 3x3 neighbourhood, no bounds tests);
+//   * discovery claims of a round are resolved in an LDS hash table (cell -> min (i*8+j)) with
+//     LDS atomics -- no global traffic -- whenever the window fits (w <= 2048);
+//   * (cost - L, ~pushOrder, cell) is packed into ONE 64-bit key, so the sort moves 8 B/element.
+// Larger windows fall back to publishing (round, rank) per cell and gathering the seven other
+// neighbours of n (exact, atomic-free, more requests); windows beyond LDS sort in HBM.
+// One workgroup per goal.  Algorithmic bytes: 9 B/cell.
 #include "pp_internal.hpp"
 
 using namespace ppd;
 
 namespace {
 
-constexpr int WF_T = 512;        // 8 waves: every access here is latency-bound, more lanes = shorter per-thread chains
-constexpr int WF_WCAP = 4096;    // LDS window capacity (48 KiB of keys+cells)
+constexpr int WF_T = 512;          // 8 waves per goal
+constexpr int WF_LCAP = 4096;      // LDS sort capacity (packed u64 keys): 32 KiB
+constexpr int WF_HCAP = 4096;      // LDS hash slots (reuses the sort buffer): windows up to 2048 cells
 constexpr uint32_t kInfBits = 0x7F800000u;
+constexpr uint32_t kOccBits = 0x7FC00000u; // NaN pattern marking occupied / border cells in the working grid
 
 struct WfSlot {
-	uint32_t* claim;     // [cells] (round+1) << 17 | rank of the cell in that round's window; 0 = never
-	uint32_t* fcell[2];  // open list ping-pong, [fcap]
+	uint32_t* grid;      // [(rows+2)*(cols+2)] working costs (padded)
+	uint32_t* tag;       // [(rows+2)*(cols+2)] (round+1) << 17 | rank, fallback claim resolution
+	uint32_t* fcell[2];  // open list ping-pong, [fcap]: padded cell index
 	uint32_t* fcost[2];
 	uint32_t* ford[2];
-	uint64_t* gkeys;     // fallback sort buffers, [gcap] (gcap = pow2 >= fcap)
+	uint64_t* gkeys;     // fallback sort buffers in HBM, [gcap] (gcap = pow2 >= fcap)
 	uint32_t* gvals;
-	uint8_t* gmask;      // [gcap]
 	uint32_t fcap, gcap;
 };
 
-__device__ __forceinline__ WfSlot slot_view(void* base, int64_t bytesPerSlot, int slot, int64_t cells, uint32_t fcap, uint32_t gcap)
+__host__ __device__ inline int64_t padded_cells(int rows, int cols) { return (int64_t)(rows + 2) * (cols + 2); }
+
+__device__ __forceinline__ WfSlot slot_view(void* base, int64_t bytesPerSlot, int slot, int64_t pcells, uint32_t fcap, uint32_t gcap)
 {
 	char* p = (char*)base + (int64_t)slot * bytesPerSlot;
 	WfSlot s;
-	s.claim = (uint32_t*)p;
-	p += cells * 4;
+	const int64_t gbytes = (pcells * 4 + 255) / 256 * 256;
+	s.grid = (uint32_t*)p;
+	p += gbytes;
+	s.tag = (uint32_t*)p;
+	p += gbytes;
 	for (int k = 0; k < 2; k++) {
 		s.fcell[k] = (uint32_t*)p;
 		p += (int64_t)fcap * 4;
@@ -58,9 +71,6 @@ __device__ __forceinline__ WfSlot slot_view(void* base, int64_t bytesPerSlot, in
 	s.gkeys = (uint64_t*)p;
 	p += (int64_t)gcap * 8;
 	s.gvals = (uint32_t*)p;
-	p += (int64_t)gcap * 4;
-	s.gmask = (uint8_t*)p;
-	p += (int64_t)gcap;
 	s.fcap = fcap;
 	s.gcap = gcap;
 	return s;
@@ -74,16 +84,41 @@ inline uint32_t next_pow2(uint32_t v)
 	return p;
 }
 
-// Bitonic sort of P (power of two) key/value pairs, ascending by key, by the whole block.
-// Wave w owns the contiguous chunk of E = P/4 elements [w*E, (w+1)*E).  A stage whose
-// partner distance j satisfies 2*j <= E only moves data inside each wave's own chunk, so two
-// such consecutive stages need no block barrier between them: a wave executes in lockstep
-// and its LDS operations complete in program order.
-__device__ __forceinline__ void cmpex(uint64_t* keys, uint32_t* vals, int t, int j, int lj, int k)
+// ---- wave-level ballot / prefix compaction: the lanes of a wave that want a slot reserve a contiguous range
+// with ONE atomic on the shared counter (a per-lane atomicAdd on one LDS word serialises ~2.4k times per round).
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, bool want)
 {
-	// j = 1 << lj: pair t of stride j is (i1, i1 + j) with i1 = (t / j) * 2j + t % j.
-	// All four reads are issued before the compare and the writes are unconditional (selects), so a
-	// compare-exchange costs one LDS round trip instead of two dependent ones.
+	const unsigned long long mask = __ballot(want);
+	if (mask == 0ull)
+		return 0u;
+	const int lane = threadIdx.x & 63;
+	const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+	uint32_t base = 0;
+	if (lane == __ffsll((long long)mask) - 1)
+		base = atomicAdd(counter, (uint32_t)__popcll(mask));
+	base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)mask) - 1);
+	return base + prefix;
+}
+
+/// LDS position of sort element i: one slot of skew per 32 elements, so that power-of-two strides (the only
+/// ones a bitonic network uses) spread over all banks instead of hitting 2-4 of them.
+__device__ __forceinline__ int SK(int i) { return i + (i >> 5); }
+constexpr int kSkewed(int n) { return n + (n >> 5); }
+
+// ---- bitonic sorts (ascending), whole block.  Wave w owns the contiguous chunk of E = P/8 elements; a
+// stage whose partner distance j satisfies 2*j <= E only moves data inside each wave's chunk, so two such
+// consecutive stages need no block barrier (a wave runs in lockstep, its LDS operations complete in order).
+__device__ __forceinline__ void cmpex1(uint64_t* keys, int t, int j, int lj, int k)
+{
+	const int i1 = ((t >> lj) << (lj + 1)) | (t & (j - 1)), i2 = i1 + j;
+	const bool up = (i1 & k) == 0;
+	const uint64_t a = keys[i1], b = keys[i2];
+	const bool sw = (a > b) == up;
+	keys[i1] = sw ? b : a;
+	keys[i2] = sw ? a : b;
+}
+__device__ __forceinline__ void cmpex2(uint64_t* keys, uint32_t* vals, int t, int j, int lj, int k)
+{
 	const int i1 = ((t >> lj) << (lj + 1)) | (t & (j - 1)), i2 = i1 + j;
 	const bool up = (i1 & k) == 0;
 	const uint64_t a = keys[i1], b = keys[i2];
@@ -95,7 +130,7 @@ __device__ __forceinline__ void cmpex(uint64_t* keys, uint32_t* vals, int t, int
 	vals[i2] = sw ? va : vb;
 }
 
-template <bool kLds>
+template <bool kLds, bool kVals>
 __device__ __forceinline__ void bitonic_sort(uint64_t* keys, uint32_t* vals, int P)
 {
 	const int tid = threadIdx.x;
@@ -107,13 +142,20 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* keys, uint32_t* vals, int
 		for (int j = k >> 1, lj = 31 - __clz(k >> 1); j > 0; j >>= 1, lj--) {
 			const bool local = canLocal && 2 * j <= E;
 			if (local) {
-				for (int t = wave * (E / 2) + lane; t < (wave + 1) * (E / 2); t += 64)
-					cmpex(keys, vals, t, j, lj, k);
+				for (int t = wave * (E / 2) + lane; t < (wave + 1) * (E / 2); t += 64) {
+					if (kVals)
+						cmpex2(keys, vals, t, j, lj, k);
+					else
+						cmpex1(keys, t, j, lj, k);
+				}
 			} else {
-				for (int t = tid; t < half; t += WF_T)
-					cmpex(keys, vals, t, j, lj, k);
+				for (int t = tid; t < half; t += WF_T) {
+					if (kVals)
+						cmpex2(keys, vals, t, j, lj, k);
+					else
+						cmpex1(keys, t, j, lj, k);
+				}
 			}
-			// the stage that follows (if any)
 			int nk = k, nj = j >> 1;
 			if (nj == 0) {
 				nk = k << 1;
@@ -130,80 +172,219 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* keys, uint32_t* vals, int
 	}
 }
 
+// ---- packed-key sort in LDS, several strides per pass.  A thread takes 2^S elements spaced by the smallest
+// stride of the pass and applies S consecutive strides of the bitonic network in registers: one LDS round trip
+// per pass instead of one per stride (the sort is LDS-latency bound: ~600 cycles per round trip at 8 waves).
+template <int S>
+__device__ __forceinline__ void bitonic_pass(uint64_t* keys, int g, int ljmin, int k)
+{
+	constexpr int N = 1 << S;
+	const int jmin = 1 << ljmin;
+	const int base = ((g >> ljmin) << (ljmin + S)) | (g & (jmin - 1));
+	const bool up = (base & k) == 0; // all N elements lie in one 2*jmax block, so they share the direction
+	uint64_t v[N];
+#pragma unroll
+	for (int e = 0; e < N; e++)
+		v[e] = keys[SK(base + e * jmin)];
+#pragma unroll
+	for (int st = S - 1; st >= 0; st--) { // stride jmin << st
+#pragma unroll
+		for (int e = 0; e < N; e++) {
+			if (!(e & (1 << st))) {
+				const int f = e | (1 << st);
+				const uint64_t a = v[e], b = v[f];
+				const bool sw = (a > b) == up;
+				v[e] = sw ? b : a;
+				v[f] = sw ? a : b;
+			}
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < N; e++)
+		keys[SK(base + e * jmin)] = v[e];
+}
+
+__device__ __forceinline__ void bitonic_sort_packed(uint64_t* keys, int P)
+{
+	const int tid = threadIdx.x;
+	const int wave = tid >> 6, lane = tid & 63;
+	const int E = P / (WF_T / 64);      // elements owned by one wave when a pass is wave-local
+	const bool canLocal = E >= 512;     // >= 64 groups of 8 per wave
+	bool prevLocal = false;
+	for (int k = 2; k <= P; k <<= 1) {
+		int lj = 31 - __clz(k >> 1); // log2 of the first (largest) stride of this merge step
+		while (lj >= 0) {
+			const int S = lj >= 2 ? 3 : lj + 1;      // strides 2^lj .. 2^(lj-S+1)
+			const int ljmin = lj - S + 1;
+			const int groups = P >> S;
+			const bool local = canLocal && (2 << lj) <= E; // 2*jmax <= E: the pass stays inside each wave's chunk
+			if (!(local && prevLocal))
+				__syncthreads();
+			else {
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+			if (local) {
+				const int gpw = E >> S; // groups per wave
+				for (int g = wave * gpw + lane; g < (wave + 1) * gpw; g += 64) {
+					if (S == 3)
+						bitonic_pass<3>(keys, g, ljmin, k);
+					else if (S == 2)
+						bitonic_pass<2>(keys, g, ljmin, k);
+					else
+						bitonic_pass<1>(keys, g, ljmin, k);
+				}
+			} else {
+				for (int g = tid; g < groups; g += WF_T) {
+					if (S == 3)
+						bitonic_pass<3>(keys, g, ljmin, k);
+					else if (S == 2)
+						bitonic_pass<2>(keys, g, ljmin, k);
+					else
+						bitonic_pass<1>(keys, g, ljmin, k);
+				}
+			}
+			prevLocal = local;
+			lj -= S;
+		}
+	}
+	__syncthreads();
+}
+
 // neighbour offsets in the reference's enumeration order (utils/grid.cpp:29-47)
 constexpr int kDr[8] = { 0, -1, 1, 0, -1, 1, -1, 1 };
 constexpr int kDc[8] = { -1, -1, -1, 1, 1, 1, 0, 0 };
 
+struct Row3 {
+	uint32_t a, b, c;
+};
+/// three consecutive 32-bit words (one request)
+__device__ __forceinline__ Row3 load_row3(const uint32_t* p)
+{
+	const float3 v = *reinterpret_cast<const float3*>(p); // 4-byte aligned 12-byte load -> global_load_dwordx3
+	Row3 r;
+	r.a = __float_as_uint(v.x);
+	r.b = __float_as_uint(v.y);
+	r.c = __float_as_uint(v.z);
+	return r;
+}
+
+/// Candidate mask of a window cell from the 3x3 block of working costs around it (heuristics.cpp:127-136):
+/// neighbour j is offered iff it is free, the corner rule allows the move and it is still undiscovered (+inf).
+__device__ __forceinline__ uint32_t candidate_mask(const Row3& up, const Row3& mid, const Row3& dn)
+{
+	const uint32_t nb[8] = { mid.a, up.a, dn.a, mid.c, up.c, dn.c, up.b, dn.b }; // order of kDr/kDc
+	const bool oL = mid.a == kOccBits, oR = mid.c == kOccBits, oU = up.b == kOccBits, oD = dn.b == kOccBits;
+	uint32_t mk = 0;
+#pragma unroll
+	for (int j = 0; j < 8; j++) {
+		bool ok = nb[j] == kInfBits; // free (not the NaN pattern) and not yet in the open list nor explored
+		// diagonal: blocked only if BOTH (n.row, cell.col) and (cell.row, n.col) are occupied (heuristics.cpp:130-132)
+		if (j == 1)
+			ok = ok && !(oU && oL);
+		if (j == 2)
+			ok = ok && !(oD && oL);
+		if (j == 4)
+			ok = ok && !(oU && oR);
+		if (j == 5)
+			ok = ok && !(oD && oR);
+		if (ok)
+			mk |= 1u << j;
+	}
+	return mk;
+}
+
 // kProfile: diagnostic build -- per goal {init, min, partition, sort, offer, push, tail} shader-clock sums + rounds, sum(w), sum(P)
 enum { WP_INIT = 0, WP_MIN, WP_PART, WP_SORT, WP_OFFER, WP_PUSH, WP_TAIL, WP_ROUNDS, WP_SUMW, WP_SUMP, WP_COUNT };
+
+#ifndef PP_WF_WAVES_PER_SIMD
+#define PP_WF_WAVES_PER_SIMD 4 // 2 workgroups of 8 waves per CU: <= 128 VGPRs
+#endif
 template <bool kProfile>
-__global__ void __launch_bounds__(WF_T) k_wavefront(MapView m, int nGoals, const int32_t* __restrict__ goalCells, float* __restrict__ costOut, void* workspace,
-	int64_t bytesPerSlot, uint32_t fcap, uint32_t gcap, int32_t* errorFlag, unsigned long long* __restrict__ prof)
+__global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapView m, int nGoals, const int32_t* __restrict__ goalCells, float* __restrict__ costOut,
+	void* workspace, int64_t bytesPerSlot, uint32_t fcap, uint32_t gcap, int32_t* errorFlag, unsigned long long* __restrict__ prof, int* __restrict__ goalCounter)
 {
 	unsigned long long ph[WP_COUNT];
 	unsigned long long tl = 0;
-#define WF_STAMP(i)                                 \
-	if (kProfile) {                                 \
-		const unsigned long long now_ = clock64();  \
-		ph[i] += now_ - tl;                         \
-		tl = now_;                                  \
+#define WF_STAMP(i)                                \
+	if (kProfile) {                                \
+		const unsigned long long now_ = clock64(); \
+		ph[i] += now_ - tl;                        \
+		tl = now_;                                 \
 	}
-	__shared__ uint64_t skey[WF_WCAP];
-	__shared__ uint32_t sval[WF_WCAP];
-	__shared__ uint8_t smask[WF_WCAP];
-	__shared__ uint32_t s_min, s_minNext, s_w, s_b, s_new;
+	__shared__ uint64_t skey[kSkewed(WF_LCAP)]; // sort buffer (skewed layout), then (as two uint32 arrays) the claim hash table
+	__shared__ uint32_t s_min, s_minNext, s_ordMin, s_ordMinNext, s_w, s_b, s_new, s_packFail, s_cand;
+	__shared__ int s_goal;
+	uint32_t* const hcell = reinterpret_cast<uint32_t*>(skey);          // [WF_HCAP] padded cell index + 1, 0 = empty
+	uint32_t* const hkey = reinterpret_cast<uint32_t*>(skey) + WF_HCAP; // [WF_HCAP] min (i*8+j)
 
 	const int tid = threadIdx.x;
-	const int64_t cells = (int64_t)m.rows * m.cols;
 	const int cols = m.cols, rows = m.rows;
-	WfSlot S = slot_view(workspace, bytesPerSlot, blockIdx.x, cells, fcap, gcap);
+	const int pc = cols + 2; // padded row stride
+	const int64_t cells = (int64_t)rows * cols;
+	const int64_t pcells = padded_cells(rows, cols);
+	WfSlot S = slot_view(workspace, bytesPerSlot, blockIdx.x, pcells, fcap, gcap);
 	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
+	const int nbOff[8] = { -1, -pc - 1, pc - 1, 1, -pc + 1, pc + 1, -pc, pc }; // padded-index offsets of kDr/kDc
 
-	for (int g = blockIdx.x; g < nGoals; g += gridDim.x) {
+	// goals are handed out dynamically: a workgroup that finishes early takes the next one (balanced tail)
+	for (;;) {
+		__syncthreads();
+		if (tid == 0)
+			s_goal = atomicAdd(goalCounter, 1);
+		__syncthreads();
+		const int g = s_goal;
+		if (g >= nGoals)
+			break;
 		if (kProfile) {
 			for (int i = 0; i < WP_COUNT; i++)
 				ph[i] = 0;
 			tl = clock64();
 		}
 		float* cost = costOut + (int64_t)g * cells;
-		uint32_t* costBits = reinterpret_cast<uint32_t*>(cost);
-		// heuristics.cpp:108-113: every cell starts at +inf / unexplored
-		{
-			uint4 inf4 = { kInfBits, kInfBits, kInfBits, kInfBits };
-			uint4 ff4 = { 0u, 0u, 0u, 0u };
-			const bool aligned = (((uintptr_t)costBits | (uintptr_t)S.claim) & 15) == 0;
-			const int64_t n4 = aligned ? cells / 4 : 0;
-			for (int64_t i = tid; i < n4; i += WF_T) {
-				reinterpret_cast<uint4*>(costBits)[i] = inf4;
-				reinterpret_cast<uint4*>(S.claim)[i] = ff4;
-			}
-			for (int64_t i = n4 * 4 + tid; i < cells; i += WF_T) {
-				costBits[i] = kInfBits;
-				S.claim[i] = 0u;
-			}
+		// ---- working grid: +inf everywhere free (heuristics.cpp:108-113), NaN pattern on occupied cells and the border
+		for (int64_t i = tid; i < pcells; i += WF_T) {
+			const int pr = (int)(i / pc), pcc = (int)(i - (int64_t)pr * pc);
+			const bool border = pr == 0 || pr == rows + 1 || pcc == 0 || pcc == cols + 1;
+			uint32_t v = kOccBits;
+			if (!border)
+				v = m.occ8[(int64_t)(pr - 1) * cols + (pcc - 1)] ? kOccBits : kInfBits;
+			S.grid[i] = v;
+			S.tag[i] = 0u;
 		}
 		const int32_t start = goalCells[g];
 		if (tid == 0) {
 			s_min = 0u; // cost bits of the start cell
 			s_minNext = 0xFFFFFFFFu;
+			s_ordMin = 0u;
+			s_ordMinNext = 0xFFFFFFFFu;
 			s_w = 0;
 			s_b = 0;
 			s_new = 0;
+			s_packFail = 0;
+			s_cand = 0;
 		}
 		__syncthreads();
-		if (start < 0)
-			continue; // goal outside the map: heuristics.cpp:115-117
+		if (start < 0) {
+			// goal outside the map (heuristics.cpp:115-117): the field stays +inf
+			for (int64_t i = tid; i < cells; i += WF_T)
+				cost[i] = __uint_as_float(kInfBits);
+			__syncthreads();
+			continue;
+		}
 		if (tid == 0) {
-			cost[start] = 0.0f;
-			S.fcell[0][0] = (uint32_t)start;
+			const int sr = start / cols, sc = start - sr * cols;
+			const uint32_t sp = (uint32_t)((sr + 1) * pc + (sc + 1));
+			S.grid[sp] = 0u; // cost 0 (the reference pushes the goal cell even when it is occupied)
+			S.fcell[0][0] = sp;
 			S.fcost[0][0] = 0u;
 			S.ford[0][0] = 0u;
 		}
 		__syncthreads();
 
 		WF_STAMP(WP_INIT);
-		uint32_t n = 1;          // open-list size
-		uint32_t roundBase = 1;  // next push-order value
+		uint32_t n = 1;         // open-list size
+		uint32_t roundBase = 1; // next push-order value
 		uint32_t round = 0;
 		int cur = 0;
 		bool overflow = false;
@@ -211,60 +392,94 @@ __global__ void __launch_bounds__(WF_T) k_wavefront(MapView m, int nGoals, const
 		while (n > 0) {
 			const int nxt = cur ^ 1;
 			// ---- L = smallest cost in the open list (tracked while the list was written in the previous round)
-			const float L = __uint_as_float(s_min);
+			const uint32_t lBits = s_min;
+			const float L = __uint_as_float(lBits);
 			const uint32_t hiBits = __float_as_uint(L + 1.0f);
+			const uint32_t ordFloor = s_ordMin;
 			WF_STAMP(WP_MIN);
-			// ---- P2: window (cost < fl(L+1)) -> sort buffer; the rest -> next open list
-			uint32_t restMin = 0xFFFFFFFFu;
-			for (uint32_t i = tid; i < n; i += WF_T) {
-				const uint32_t c = S.fcost[cur][i], cell = S.fcell[cur][i], ord = S.ford[cur][i];
-				if (c < hiBits) {
-					const uint32_t slot = atomicAdd(&s_w, 1u);
-					const uint64_t key = ((uint64_t)c << 32) | (uint64_t)(0xFFFFFFFFu - ord);
-					if (slot < WF_WCAP) {
-						skey[slot] = key;
-						sval[slot] = cell;
-					} else if (slot < S.gcap) {
-						S.gkeys[slot] = key;
-						S.gvals[slot] = cell;
+			// ---- partition: window (cost < fl(L+1)) -> sort buffer; the rest -> next open list.
+			// Window entries are packed as (cost - L : 23 | ~(order - floor) : 20 | cell : 21) in LDS; when a round does
+			// not fit that encoding (or the LDS buffer) the partition is redone into the unpacked HBM buffers.
+			const bool packable = pcells <= (1 << 21);
+			bool fast = true;
+			uint32_t w = 0, b = 0;
+			for (int attempt = 0; attempt < 2; attempt++) {
+				uint32_t restMin = 0xFFFFFFFFu, restOrd = 0xFFFFFFFFu;
+				for (uint32_t i0 = 0; i0 < n; i0 += 8 * WF_T) {
+					// the loads of up to 8 entries are issued before any is used
+					uint32_t ec[8], ecell[8], eord[8];
+#pragma unroll
+					for (int u = 0; u < 8; u++) {
+						const uint32_t i = i0 + u * WF_T + tid;
+						const bool in = i < n;
+						ec[u] = in ? S.fcost[cur][i] : 0xFFFFFFFFu;
+						ecell[u] = in ? S.fcell[cur][i] : 0u;
+						eord[u] = in ? S.ford[cur][i] : 0u;
 					}
-				} else {
-					const uint32_t slot = atomicAdd(&s_b, 1u);
-					S.fcell[nxt][slot] = cell; // slot < n <= fcap
-					S.fcost[nxt][slot] = c;
-					S.ford[nxt][slot] = ord;
-					restMin = min(restMin, c);
+#pragma unroll
+					for (int u = 0; u < 8; u++) {
+						const uint32_t i = i0 + u * WF_T + tid;
+						const bool in = i < n;
+						const uint32_t c = ec[u], cell = ecell[u], ord = eord[u];
+						const bool inWindow = in && c < hiBits;
+						const bool inRest = in && !inWindow;
+						const uint32_t wslot = wave_alloc(&s_w, inWindow);
+						const uint32_t bslot = wave_alloc(&s_b, inRest);
+						if (inWindow) {
+							if (fast) {
+								const uint32_t rel = ord - ordFloor;
+								if (!packable || rel >= (1u << 20) || (c - lBits) >= (1u << 23))
+									s_packFail = 1;
+								if (wslot < WF_LCAP)
+									skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0xFFFFFu - (rel & 0xFFFFFu)) << 21) | (uint64_t)cell;
+							} else if (wslot < S.gcap) {
+								S.gkeys[wslot] = ((uint64_t)c << 32) | (uint64_t)(0xFFFFFFFFu - ord);
+								S.gvals[wslot] = cell;
+							}
+						} else if (inRest) {
+							S.fcell[nxt][bslot] = cell; // bslot < n <= fcap
+							S.fcost[nxt][bslot] = c;
+							S.ford[nxt][bslot] = ord;
+							restMin = min(restMin, c);
+							restOrd = min(restOrd, ord);
+						}
+					}
 				}
+				if (restMin != 0xFFFFFFFFu) {
+					atomicMin(&s_minNext, restMin);
+					atomicMin(&s_ordMinNext, restOrd);
+				}
+				__syncthreads();
+				w = s_w;
+				b = s_b;
+				const bool ok = !s_packFail && w <= WF_LCAP;
+				__syncthreads();
+				if (!fast || ok)
+					break;
+				fast = false; // redo into the HBM buffers
+				if (tid == 0) {
+					s_w = 0;
+					s_b = 0;
+				}
+				__syncthreads();
 			}
-			if (restMin != 0xFFFFFFFFu)
-				atomicMin(&s_minNext, restMin);
-			__syncthreads();
-			const uint32_t w = s_w, b = s_b;
 			WF_STAMP(WP_PART);
-			if (w > S.gcap) {
+			if (w > S.gcap || round + 1u >= (1u << 15) || w > (1u << 17)) {
 				overflow = true;
 				break;
 			}
-			const bool lds = w <= WF_WCAP;
-			uint64_t* keys = lds ? skey : S.gkeys;
-			uint32_t* vals = lds ? sval : S.gvals;
-			uint8_t* mask = lds ? smask : S.gmask;
 			const uint32_t P = w <= 1 ? 2 : (1u << (32 - __clz((int)(w - 1))));
-			if (lds) {
-				for (uint32_t i = w + tid; i < P; i += WF_T)
-					skey[i] = ~0ull;
+			if (fast) {
+				for (uint32_t i = w + tid; i < (P < 8 ? 8u : P); i += WF_T)
+					skey[SK((int)i)] = ~0ull;
 				__syncthreads();
 				if (w > 1)
-					bitonic_sort<true>(skey, sval, (int)P);
+					bitonic_sort_packed(skey, (int)(P < 8 ? 8 : P));
 			} else {
-				for (uint32_t i = tid; i < WF_WCAP; i += WF_T) {
-					S.gkeys[i] = skey[i];
-					S.gvals[i] = sval[i];
-				}
 				for (uint32_t i = w + tid; i < P; i += WF_T)
 					S.gkeys[i] = ~0ull;
 				__syncthreads();
-				bitonic_sort<false>(S.gkeys, S.gvals, (int)P);
+				bitonic_sort<false, true>(S.gkeys, S.gvals, (int)P);
 			}
 			WF_STAMP(WP_SORT);
 			if (kProfile) {
@@ -272,114 +487,196 @@ __global__ void __launch_bounds__(WF_T) k_wavefront(MapView m, int nGoals, const
 				ph[WP_SUMW] += w;
 				ph[WP_SUMP] += P;
 			}
-			// ---- P3a: publish (round, rank) of every window cell
-			if (round + 1u >= (1u << 15) || w > (1u << 17)) {
-				overflow = true;
-				break;
-			}
-			const uint32_t roundTag = (round + 1u) << 17;
-			for (uint32_t i = tid; i < w; i += WF_T)
-				S.claim[vals[i]] = roundTag | i;
-			__syncthreads();
-			WF_STAMP(WP_OFFER);
-			// ---- P3b: every window cell, in pop order i, offers itself to its undiscovered neighbours and
-			// pushes the ones it discovers first: cost fixed at discovery (Q3), push order = roundBase + i*8 + j.
-			// Reads are issued in batches before use (one memory round trip per batch).
-			uint32_t newMin = 0xFFFFFFFFu;
-			for (uint32_t i = tid; i < w; i += WF_T) {
-				const uint32_t cell = vals[i];
-				const int r = (int)(cell / (uint32_t)cols), c = (int)(cell - (uint32_t)r * (uint32_t)cols);
-				const float ci = __uint_as_float((uint32_t)(keys[i] >> 32));
-				int64_t nidx[8];
-				uint8_t occ[8];
-				uint32_t cb[8];
-				bool inb[8];
+			uint32_t newMin = 0xFFFFFFFFu, newOrd = 0xFFFFFFFFu;
+			// The claim table has WF_HCAP slots; the round may use it only when every candidate (counted with
+			// duplicates, so an upper bound on distinct cells) fits with room to spare: insertion then always ends.
+			uint32_t myCell[4] = { 0, 0, 0, 0 }, myCost[4] = { 0, 0, 0, 0 }, myMask[4] = { 0, 0, 0, 0 };
+			bool hashed = false;
+			if (fast && w <= 4u * WF_T) {
+				Row3 up[4], mid[4], dn[4];
 #pragma unroll
-				for (int j = 0; j < 8; j++) {
-					const int nr = r + kDr[j], nc = c + kDc[j];
-					inb[j] = nr >= 0 && nr < rows && nc >= 0 && nc < cols;
-					nidx[j] = inb[j] ? (int64_t)nr * cols + nc : (int64_t)cell;
-				}
-#pragma unroll
-				for (int j = 0; j < 8; j++) {
-					occ[j] = m.occ8[nidx[j]];
-					cb[j] = costBits[nidx[j]];
-				}
-#pragma unroll
-				for (int j = 0; j < 8; j++) {
-					bool ok = inb[j] && !occ[j]; // IsOccupied(n), heuristics.cpp:128-129
-					// diagonal: blocked only if BOTH orthogonal cells (n.row, cell.col) and (cell.row, n.col) are occupied (:130-132);
-					// they are neighbours 6/7 (row -/+ 1) and 0/3 (col -/+ 1) of this cell, in bounds whenever the diagonal is
-					if (j == 1)
-						ok = ok && !(occ[6] && occ[0]);
-					if (j == 2)
-						ok = ok && !(occ[7] && occ[0]);
-					if (j == 4)
-						ok = ok && !(occ[6] && occ[3]);
-					if (j == 5)
-						ok = ok && !(occ[7] && occ[3]);
-					ok = ok && cb[j] == kInfBits; // not yet in the open list nor explored
-					if (!ok)
-						continue;
-					// n = neighbour j of this cell.  Is another window cell the first to reach n?
-					const int nr = r + kDr[j], nc = c + kDc[j];
-					const uint32_t mine = i * 8u + (uint32_t)j;
-					uint32_t tag[8];
-					uint8_t no[4]; // occupancy of n's orthogonal neighbours: (nr, nc-1), (nr, nc+1), (nr-1, nc), (nr+1, nc)
-#pragma unroll
-					for (int jj = 0; jj < 8; jj++) {
-						// p'' = n - d_jj reaches n through direction jj
-						const int pr = nr - kDr[jj], pc = nc - kDc[jj];
-						const bool pin = pr >= 0 && pr < rows && pc >= 0 && pc < cols && jj != j;
-						tag[jj] = pin ? S.claim[(int64_t)pr * cols + pc] : 0u;
+				for (int q = 0; q < 4; q++) {
+					const uint32_t i = tid + q * WF_T;
+					if (i < w) {
+						const uint64_t k = skey[SK((int)i)];
+						myCell[q] = (uint32_t)(k & 0x1FFFFFu);
+						myCost[q] = lBits + (uint32_t)(k >> 41);
+						const uint32_t* base = S.grid + myCell[q];
+						up[q] = load_row3(base - pc - 1);
+						mid[q] = load_row3(base - 1);
+						dn[q] = load_row3(base + pc - 1);
 					}
-					no[0] = (nc - 1 >= 0) ? m.occ8[(int64_t)nr * cols + (nc - 1)] : (uint8_t)1;
-					no[1] = (nc + 1 < cols) ? m.occ8[(int64_t)nr * cols + (nc + 1)] : (uint8_t)1;
-					no[2] = (nr - 1 >= 0) ? m.occ8[(int64_t)(nr - 1) * cols + nc] : (uint8_t)1;
-					no[3] = (nr + 1 < rows) ? m.occ8[(int64_t)(nr + 1) * cols + nc] : (uint8_t)1;
-					bool win = true;
+				}
+				uint32_t cnt = 0;
 #pragma unroll
-					for (int jj = 0; jj < 8; jj++) {
-						if ((tag[jj] & 0xFFFE0000u) != roundTag)
-							continue; // not popped in this round
-						// corner rule for p'' -> n: both (n.row, p''.col) and (p''.row, n.col) occupied blocks a diagonal move
-						bool allowed = true;
-						if (kDr[jj] != 0 && kDc[jj] != 0) {
-							const uint8_t oc = kDc[jj] > 0 ? no[0] : no[1]; // (nr, nc - dc)
-							const uint8_t orr = kDr[jj] > 0 ? no[2] : no[3]; // (nr - dr, nc)
-							allowed = !(oc && orr);
+				for (int q = 0; q < 4; q++) {
+					const uint32_t i = tid + q * WF_T;
+					if (i < w) {
+						myMask[q] = candidate_mask(up[q], mid[q], dn[q]);
+						cnt += __popc(myMask[q]);
+					}
+				}
+				for (int off = 32; off > 0; off >>= 1)
+					cnt += __shfl_xor((int)cnt, off, 64);
+				if ((tid & 63) == 0 && cnt)
+					atomicAdd(&s_cand, cnt);
+				__syncthreads();
+				hashed = s_cand <= (uint32_t)(WF_HCAP * 3 / 4);
+			}
+			if (hashed) {
+				// ================= fast path: claims in an LDS hash table (the sort buffer is reused) =================
+				for (int i = tid; i < WF_HCAP; i += WF_T) {
+					hcell[i] = 0u;
+					hkey[i] = 0xFFFFFFFFu;
+				}
+				__syncthreads();
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const uint32_t i = tid + q * WF_T;
+					const uint32_t mk = myMask[q];
+					if (i < w && mk) {
+#pragma unroll
+						for (int j = 0; j < 8; j++) {
+							if (!(mk & (1u << j)))
+								continue;
+							const uint32_t ncell = myCell[q] + (uint32_t)nbOff[j];
+							const uint32_t key = i * 8u + (uint32_t)j;
+							uint32_t h = (ncell * 2654435761u) >> (32 - 12); // WF_HCAP = 4096 = 2^12
+							for (;;) {
+								const uint32_t old = atomicCAS(&hcell[h], 0u, ncell + 1u);
+								if (old == 0u || old == ncell + 1u) {
+									atomicMin(&hkey[h], key);
+									break;
+								}
+								h = (h + 1) & (WF_HCAP - 1);
+							}
 						}
-						const uint32_t other = (tag[jj] & 0x1FFFFu) * 8u + (uint32_t)jj;
-						if (allowed && other < mine)
-							win = false;
 					}
-					if (!win)
-						continue;
-					const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
-					const float pathCost = transitionCost + ci; // heuristics.cpp:135
-					cost[nidx[j]] = pathCost;
-					newMin = min(newMin, __float_as_uint(pathCost));
-					const uint32_t slot = b + atomicAdd(&s_new, 1u);
-					if (slot < S.fcap) {
-						S.fcell[nxt][slot] = (uint32_t)nidx[j];
-						S.fcost[nxt][slot] = __float_as_uint(pathCost);
-						S.ford[nxt][slot] = roundBase + mine;
+				}
+				__syncthreads();
+				WF_STAMP(WP_OFFER);
+				// push the winners: cost fixed at discovery (Q3), push order = roundBase + i*8 + j.  Uniform control flow:
+				// every lane takes part in the ballot that hands out open-list slots (one LDS atomic per wave).
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const uint32_t i = tid + q * WF_T;
+					const uint32_t mk = (i < w) ? myMask[q] : 0u;
+					const float ci = __uint_as_float(myCost[q]);
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						const bool cand = (mk & (1u << j)) != 0u;
+						const uint32_t ncell = myCell[q] + (uint32_t)nbOff[j];
+						const uint32_t key = i * 8u + (uint32_t)j;
+						bool win = false;
+						if (cand) {
+							uint32_t h = (ncell * 2654435761u) >> (32 - 12);
+							while (hcell[h] != ncell + 1u)
+								h = (h + 1) & (WF_HCAP - 1);
+							win = hkey[h] == key;
+						}
+						const uint32_t slot = b + wave_alloc(&s_new, win);
+						if (win) {
+							const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
+							const float pathCost = transitionCost + ci; // heuristics.cpp:135
+							const uint32_t pb = __float_as_uint(pathCost);
+							S.grid[ncell] = pb;
+							newMin = min(newMin, pb);
+							newOrd = min(newOrd, roundBase + key);
+							if (slot < S.fcap) {
+								S.fcell[nxt][slot] = ncell;
+								S.fcost[nxt][slot] = pb;
+								S.ford[nxt][slot] = roundBase + key;
+							}
+						}
+					}
+				}
+			} else {
+				// ================= fallback: publish (round, rank), gather the other neighbours of n =================
+				const uint32_t roundTag = (round + 1u) << 17;
+				for (uint32_t i = tid; i < w; i += WF_T) {
+					const uint32_t cell = fast ? (uint32_t)(skey[SK((int)i)] & 0x1FFFFFu) : S.gvals[i];
+					S.tag[cell] = roundTag | i;
+				}
+				__syncthreads();
+				WF_STAMP(WP_OFFER);
+				for (uint32_t i = tid; i < w; i += WF_T) {
+					uint32_t cell, cbits;
+					if (fast) {
+						const uint64_t k = skey[SK((int)i)];
+						cell = (uint32_t)(k & 0x1FFFFFu);
+						cbits = lBits + (uint32_t)(k >> 41);
+					} else {
+						cell = S.gvals[i];
+						cbits = (uint32_t)(S.gkeys[i] >> 32);
+					}
+					const float ci = __uint_as_float(cbits);
+					const uint32_t* base = S.grid + cell;
+					const Row3 up = load_row3(base - pc - 1), mid = load_row3(base - 1), dn = load_row3(base + pc - 1);
+					const uint32_t mk = candidate_mask(up, mid, dn);
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						if (!(mk & (1u << j)))
+							continue;
+						// n = neighbour j.  Is another window cell the first to reach n?
+						const uint32_t ncell = cell + (uint32_t)nbOff[j];
+						const uint32_t mine = i * 8u + (uint32_t)j;
+						const Row3 tu = load_row3(S.tag + ncell - pc - 1), tm = load_row3(S.tag + ncell - 1), td = load_row3(S.tag + ncell + pc - 1);
+						const Row3 gu = load_row3(S.grid + ncell - pc - 1), gm = load_row3(S.grid + ncell - 1), gd = load_row3(S.grid + ncell + pc - 1);
+						// p'' = n - d_jj reaches n through direction jj: p'' sits at offset -d_jj from n
+						const uint32_t tg[8] = { tm.c, td.c, tu.c, tm.a, td.a, tu.a, td.b, tu.b };
+						const bool oL = gm.a == kOccBits, oR = gm.c == kOccBits, oU = gu.b == kOccBits, oD = gd.b == kOccBits; // n's orthogonal neighbours
+						bool win = true;
+#pragma unroll
+						for (int jj = 0; jj < 8; jj++) {
+							if (jj == j || (tg[jj] & 0xFFFE0000u) != roundTag)
+								continue; // itself, or not popped in this round
+							// corner rule for p'' -> n: (n.row, p''.col) = (nr, nc - dc) and (p''.row, n.col) = (nr - dr, nc)
+							bool allowed = true;
+							if (kDr[jj] != 0 && kDc[jj] != 0) {
+								const bool oc = kDc[jj] > 0 ? oL : oR;
+								const bool orr = kDr[jj] > 0 ? oU : oD;
+								allowed = !(oc && orr);
+							}
+							const uint32_t other = (tg[jj] & 0x1FFFFu) * 8u + (uint32_t)jj;
+							if (allowed && other < mine)
+								win = false;
+						}
+						if (!win)
+							continue;
+						const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
+						const float pathCost = transitionCost + ci; // heuristics.cpp:135
+						const uint32_t pb = __float_as_uint(pathCost);
+						S.grid[ncell] = pb;
+						newMin = min(newMin, pb);
+						newOrd = min(newOrd, roundBase + mine);
+						const uint32_t slot = b + atomicAdd(&s_new, 1u);
+						if (slot < S.fcap) {
+							S.fcell[nxt][slot] = ncell;
+							S.fcost[nxt][slot] = pb;
+							S.ford[nxt][slot] = roundBase + mine;
+						}
 					}
 				}
 			}
-			if (newMin != 0xFFFFFFFFu)
+			if (newMin != 0xFFFFFFFFu) {
 				atomicMin(&s_minNext, newMin);
+				atomicMin(&s_ordMinNext, newOrd);
+			}
 			__syncthreads();
 			WF_STAMP(WP_PUSH);
 			const uint32_t nn = b + s_new;
-			const uint32_t nextMin = s_minNext;
+			const uint32_t nextMin = s_minNext, nextOrd = s_ordMinNext;
 			__syncthreads();
 			if (tid == 0) {
 				s_min = nextMin;
 				s_minNext = 0xFFFFFFFFu;
+				s_ordMin = nextOrd;
+				s_ordMinNext = 0xFFFFFFFFu;
 				s_w = 0;
 				s_b = 0;
 				s_new = 0;
+				s_packFail = 0;
+				s_cand = 0;
 			}
 			__syncthreads();
 			if (nn > S.fcap) {
@@ -392,13 +689,21 @@ __global__ void __launch_bounds__(WF_T) k_wavefront(MapView m, int nGoals, const
 			cur = nxt;
 			WF_STAMP(WP_TAIL);
 		}
+		if (overflow && tid == 0)
+			*errorFlag = 1; // open list / round count beyond the workspace encoding
+		__syncthreads();
+		// ---- result: unpadded field, +inf where the reference leaves the cell unexplored (occupied or unreachable)
+		for (int64_t i = tid; i < cells; i += WF_T) {
+			const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+			const uint32_t v = S.grid[(int64_t)(r + 1) * pc + (c + 1)];
+			cost[i] = __uint_as_float(v == kOccBits ? kInfBits : v);
+		}
+		__syncthreads();
 		if (kProfile && tid == 0)
 			for (int i = 0; i < WP_COUNT; i++)
 				prof[(size_t)g * WP_COUNT + i] = ph[i];
-		if (overflow && tid == 0)
-			*errorFlag = 1; // open list larger than the workspace
-		__syncthreads();
 	}
+#undef WF_STAMP
 }
 
 } // namespace
@@ -419,9 +724,20 @@ int64_t wavefront_workspace_bytes(int rows, int cols)
 {
 	uint32_t fcap, gcap;
 	wf_caps(rows, cols, fcap, gcap);
-	int64_t cells = (int64_t)rows * cols;
-	int64_t b = cells * 4 + 6ll * fcap * 4 + (int64_t)gcap * 13 + 16;
+	const int64_t gbytes = (padded_cells(rows, cols) * 4 + 255) / 256 * 256;
+	int64_t b = 2 * gbytes + 6ll * fcap * 4 + (int64_t)gcap * 12 + 16;
 	return (b + 255) / 256 * 256;
+}
+
+int wavefront_resident_blocks()
+{
+	int perCu = 0, dev = 0;
+	hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+		return 256;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront<false>, WF_T, 0) != hipSuccess || perCu < 1)
+		perCu = 1;
+	return perCu * prop.multiProcessorCount;
 }
 
 hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
@@ -432,12 +748,16 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 	uint32_t fcap, gcap;
 	wf_caps(m.rows, m.cols, fcap, gcap);
 	int grid = nGoals < nSlots ? nGoals : nSlots;
+	// errorFlagDev[0] = overflow flag, errorFlagDev[1] = next-goal counter
+	hipError_t e = hipMemsetAsync(errorFlagDev + 1, 0, sizeof(int), s);
+	if (e != hipSuccess)
+		return e;
 	if (profDev)
 		hipLaunchKernelGGL(k_wavefront<true>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev);
+			profDev, (int*)(errorFlagDev + 1));
 	else
 		hipLaunchKernelGGL(k_wavefront<false>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev);
+			profDev, (int*)(errorFlagDev + 1));
 	return hipGetLastError();
 }
 
