@@ -32,7 +32,8 @@ def build(force=False, verbose=True):
     if not force and not stale():
         return LIB
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("PP_EXTRA_HIPCC_FLAGS", "").split()  # tuning experiments, e.g. -DPP_WF_WAVES_PER_SIMD=2
+    cmd = [hipcc()] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd, cwd=CSRC)

@@ -49,7 +49,7 @@ struct WfSlot {
 	uint32_t fcap, gcap;
 };
 
-__host__ __device__ inline int64_t padded_cells(int rows, int cols) { return (int64_t)(rows + 2) * (cols + 2); }
+__host__ __device__ inline int64_t padded_cells(int rows, int cols) { return (int64_t)(rows + 2) * ((cols + 2 + 7) & ~7); }
 
 __device__ __forceinline__ WfSlot slot_view(void* base, int64_t bytesPerSlot, int slot, int64_t pcells, uint32_t fcap, uint32_t gcap)
 {
@@ -255,13 +255,30 @@ __device__ __forceinline__ void bitonic_sort_packed(uint64_t* keys, int P)
 constexpr int kDr[8] = { 0, -1, 1, 0, -1, 1, -1, 1 };
 constexpr int kDc[8] = { -1, -1, -1, 1, 1, 1, 0, 0 };
 
+/// three consecutive state bytes (c-1, c, c+1) of one padded row, fetched as ONE aligned 8-byte word:
+/// base4 = (c-1) & ~3 always covers c-1 .. c+1 (offset <= 3, so offset + 2 <= 5 < 8)
 struct Row3 {
 	uint32_t a, b, c;
 };
-/// three consecutive 32-bit words (one request)
+__device__ __forceinline__ Row3 load_state3(const uint8_t* rowBase, int cm1)
+{
+	const int base4 = cm1 & ~3;
+	struct __attribute__((aligned(4))) U2 {
+		uint32_t x, y;
+	};
+	const U2 v = *reinterpret_cast<const U2*>(rowBase + base4); // 4-byte aligned: row stride is a multiple of 8 bytes
+	const unsigned long long w = ((unsigned long long)v.y << 32) | v.x;
+	const int sh = (cm1 - base4) * 8;
+	Row3 r;
+	r.a = (uint32_t)(w >> sh) & 0xFFu;
+	r.b = (uint32_t)(w >> (sh + 8)) & 0xFFu;
+	r.c = (uint32_t)(w >> (sh + 16)) & 0xFFu;
+	return r;
+}
+/// three consecutive 32-bit words (fallback path: rank words)
 __device__ __forceinline__ Row3 load_row3(const uint32_t* p)
 {
-	const float3 v = *reinterpret_cast<const float3*>(p); // 4-byte aligned 12-byte load -> global_load_dwordx3
+	const float3 v = *reinterpret_cast<const float3*>(p);
 	Row3 r;
 	r.a = __float_as_uint(v.x);
 	r.b = __float_as_uint(v.y);
@@ -269,16 +286,18 @@ __device__ __forceinline__ Row3 load_row3(const uint32_t* p)
 	return r;
 }
 
-/// Candidate mask of a window cell from the 3x3 block of working costs around it (heuristics.cpp:127-136):
-/// neighbour j is offered iff it is free, the corner rule allows the move and it is still undiscovered (+inf).
+constexpr uint32_t ST_FREE = 0u, ST_OCC = 1u, ST_SEEN = 2u; // state grid values (border = ST_OCC)
+
+/// Candidate mask of a window cell from the 3x3 block of states around it (heuristics.cpp:127-136):
+/// neighbour j is offered iff it is free and undiscovered and the corner rule allows the move.
 __device__ __forceinline__ uint32_t candidate_mask(const Row3& up, const Row3& mid, const Row3& dn)
 {
 	const uint32_t nb[8] = { mid.a, up.a, dn.a, mid.c, up.c, dn.c, up.b, dn.b }; // order of kDr/kDc
-	const bool oL = mid.a == kOccBits, oR = mid.c == kOccBits, oU = up.b == kOccBits, oD = dn.b == kOccBits;
+	const bool oL = mid.a == ST_OCC, oR = mid.c == ST_OCC, oU = up.b == ST_OCC, oD = dn.b == ST_OCC;
 	uint32_t mk = 0;
 #pragma unroll
 	for (int j = 0; j < 8; j++) {
-		bool ok = nb[j] == kInfBits; // free (not the NaN pattern) and not yet in the open list nor explored
+		bool ok = nb[j] == ST_FREE; // not occupied, not yet in the open list nor explored
 		// diagonal: blocked only if BOTH (n.row, cell.col) and (cell.row, n.col) are occupied (heuristics.cpp:130-132)
 		if (j == 1)
 			ok = ok && !(oU && oL);
@@ -295,7 +314,9 @@ __device__ __forceinline__ uint32_t candidate_mask(const Row3& up, const Row3& m
 }
 
 // kProfile: diagnostic build -- per goal {init, min, partition, sort, offer, push, tail} shader-clock sums + rounds, sum(w), sum(P)
-enum { WP_INIT = 0, WP_MIN, WP_PART, WP_SORT, WP_OFFER, WP_PUSH, WP_TAIL, WP_ROUNDS, WP_SUMW, WP_SUMP, WP_COUNT };
+enum { WP_INIT = 0, WP_MIN, WP_PART, WP_SORT, WP_OFFER, WP_PUSH, WP_TAIL, WP_ROUNDS, WP_SUMW, WP_SUMP, WP_FBROUNDS, WP_FBCYC, WP_COUNT };
+
+constexpr int WF_LIST = 3072; // open-list entries kept in LDS (36 KiB); beyond that the list lives in HBM
 
 #ifndef PP_WF_WAVES_PER_SIMD
 #define PP_WF_WAVES_PER_SIMD 4 // 2 workgroups of 8 waves per CU: <= 128 VGPRs
@@ -313,20 +334,24 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		tl = now_;                                 \
 	}
 	__shared__ uint64_t skey[kSkewed(WF_LCAP)]; // sort buffer (skewed layout), then (as two uint32 arrays) the claim hash table
-	__shared__ uint32_t s_min, s_minNext, s_ordMin, s_ordMinNext, s_w, s_b, s_new, s_packFail, s_cand;
+	__shared__ uint64_t lco[WF_LIST];            // open list in LDS: cost bits << 32 | push order
+	__shared__ uint32_t lcell[WF_LIST];          //                   padded cell index
+	__shared__ uint32_t s_min, s_minNext, s_ordMin, s_ordMinNext, s_w, s_b, s_new, s_packFail, s_cand, s_distinct;
 	__shared__ int s_goal;
 	uint32_t* const hcell = reinterpret_cast<uint32_t*>(skey);          // [WF_HCAP] padded cell index + 1, 0 = empty
 	uint32_t* const hkey = reinterpret_cast<uint32_t*>(skey) + WF_HCAP; // [WF_HCAP] min (i*8+j)
 
 	const int tid = threadIdx.x;
 	const int cols = m.cols, rows = m.rows;
-	const int pc = cols + 2; // padded row stride
+	const int pc = (cols + 2 + 7) & ~7; // padded row stride of the state grid (bytes), multiple of 8
 	const int64_t cells = (int64_t)rows * cols;
-	const int64_t pcells = padded_cells(rows, cols);
+	const int64_t pcells = (int64_t)(rows + 2) * pc;
 	WfSlot S = slot_view(workspace, bytesPerSlot, blockIdx.x, pcells, fcap, gcap);
+	uint8_t* const state = reinterpret_cast<uint8_t*>(S.grid); // [(rows+2) * pc] bytes
 	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
 	const int nbOff[8] = { -1, -pc - 1, pc - 1, 1, -pc + 1, pc + 1, -pc, pc }; // padded-index offsets of kDr/kDc
 
+	int tagGoal = -1; // goal whose fallback rounds the tag grid currently describes (it is cleared lazily)
 	// goals are handed out dynamically: a workgroup that finishes early takes the next one (balanced tail)
 	for (;;) {
 		__syncthreads();
@@ -342,15 +367,18 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			tl = clock64();
 		}
 		float* cost = costOut + (int64_t)g * cells;
-		// ---- working grid: +inf everywhere free (heuristics.cpp:108-113), NaN pattern on occupied cells and the border
-		for (int64_t i = tid; i < pcells; i += WF_T) {
-			const int pr = (int)(i / pc), pcc = (int)(i - (int64_t)pr * pc);
-			const bool border = pr == 0 || pr == rows + 1 || pcc == 0 || pcc == cols + 1;
-			uint32_t v = kOccBits;
-			if (!border)
-				v = m.occ8[(int64_t)(pr - 1) * cols + (pcc - 1)] ? kOccBits : kInfBits;
-			S.grid[i] = v;
-			S.tag[i] = 0u;
+		uint32_t* costBits = reinterpret_cast<uint32_t*>(cost);
+		// ---- every cell starts at +inf / unexplored (heuristics.cpp:108-113); state: occupied cells and the border
+		for (int64_t i = tid; i < cells; i += WF_T)
+			costBits[i] = kInfBits;
+		for (int pr = 0; pr < rows + 2; pr++) {
+			const bool brow = pr == 0 || pr == rows + 1;
+			for (int pcc = tid; pcc < pc; pcc += WF_T) {
+				uint8_t v = (uint8_t)ST_OCC;
+				if (!brow && pcc >= 1 && pcc <= cols)
+					v = m.occ8[(int64_t)(pr - 1) * cols + (pcc - 1)] ? (uint8_t)ST_OCC : (uint8_t)ST_FREE;
+				state[(int64_t)pr * pc + pcc] = v;
+			}
 		}
 		const int32_t start = goalCells[g];
 		if (tid == 0) {
@@ -363,22 +391,18 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			s_new = 0;
 			s_packFail = 0;
 			s_cand = 0;
+			s_distinct = 0;
 		}
 		__syncthreads();
-		if (start < 0) {
-			// goal outside the map (heuristics.cpp:115-117): the field stays +inf
-			for (int64_t i = tid; i < cells; i += WF_T)
-				cost[i] = __uint_as_float(kInfBits);
-			__syncthreads();
-			continue;
-		}
+		if (start < 0)
+			continue; // goal outside the map (heuristics.cpp:115-117): the field stays +inf
 		if (tid == 0) {
 			const int sr = start / cols, sc = start - sr * cols;
 			const uint32_t sp = (uint32_t)((sr + 1) * pc + (sc + 1));
-			S.grid[sp] = 0u; // cost 0 (the reference pushes the goal cell even when it is occupied)
-			S.fcell[0][0] = sp;
-			S.fcost[0][0] = 0u;
-			S.ford[0][0] = 0u;
+			state[sp] = (uint8_t)ST_SEEN; // the reference pushes the goal cell even when it is occupied
+			cost[start] = 0.0f;
+			lco[0] = 0ull; // cost 0, order 0
+			lcell[0] = sp;
 		}
 		__syncthreads();
 
@@ -386,7 +410,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		uint32_t n = 1;         // open-list size
 		uint32_t roundBase = 1; // next push-order value
 		uint32_t round = 0;
-		int cur = 0;
+		bool inLds = true;      // where the open list lives
+		int cur = 0;            // ping-pong index of the HBM list
 		bool overflow = false;
 
 		while (n > 0) {
@@ -397,25 +422,55 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			const uint32_t hiBits = __float_as_uint(L + 1.0f);
 			const uint32_t ordFloor = s_ordMin;
 			WF_STAMP(WP_MIN);
-			// ---- partition: window (cost < fl(L+1)) -> sort buffer; the rest -> next open list.
+			// ---- partition: window (cost < fl(L+1)) -> sort buffer; the rest stays in the open list.
 			// Window entries are packed as (cost - L : 23 | ~(order - floor) : 20 | cell : 21) in LDS; when a round does
-			// not fit that encoding (or the LDS buffer) the partition is redone into the unpacked HBM buffers.
+			// not fit that encoding (or the LDS buffer) the window goes to the unpacked HBM buffers instead.
 			const bool packable = pcells <= (1 << 21);
 			bool fast = true;
 			uint32_t w = 0, b = 0;
 			for (int attempt = 0; attempt < 2; attempt++) {
 				uint32_t restMin = 0xFFFFFFFFu, restOrd = 0xFFFFFFFFu;
 				for (uint32_t i0 = 0; i0 < n; i0 += 8 * WF_T) {
-					// the loads of up to 8 entries are issued before any is used
+					// up to 8 entries per thread are read before any is written back (in-place compaction of the LDS list)
 					uint32_t ec[8], ecell[8], eord[8];
 #pragma unroll
 					for (int u = 0; u < 8; u++) {
 						const uint32_t i = i0 + u * WF_T + tid;
 						const bool in = i < n;
-						ec[u] = in ? S.fcost[cur][i] : 0xFFFFFFFFu;
-						ecell[u] = in ? S.fcell[cur][i] : 0u;
-						eord[u] = in ? S.ford[cur][i] : 0u;
+						if (inLds) {
+							const uint64_t e = in ? lco[i] : ~0ull;
+							ec[u] = (uint32_t)(e >> 32);
+							eord[u] = (uint32_t)e;
+							ecell[u] = in ? lcell[i] : 0u;
+						} else {
+							ec[u] = in ? S.fcost[cur][i] : 0xFFFFFFFFu;
+							ecell[u] = in ? S.fcell[cur][i] : 0u;
+							eord[u] = in ? S.ford[cur][i] : 0u;
+						}
 					}
+					if (inLds)
+						__syncthreads(); // all reads of this chunk done before survivors are compacted over it
+					// one pair of LDS atomics per wave and chunk: ballots first, then the slots follow from lane prefixes
+					unsigned long long bwM[8], brM[8];
+					uint32_t wTot = 0, rTot = 0;
+#pragma unroll
+					for (int u = 0; u < 8; u++) {
+						const bool in = i0 + u * WF_T + tid < n;
+						bwM[u] = __ballot(in && ec[u] < hiBits);
+						brM[u] = __ballot(in && !(ec[u] < hiBits));
+						wTot += (uint32_t)__popcll(bwM[u]);
+						rTot += (uint32_t)__popcll(brM[u]);
+					}
+					uint32_t wBase = 0, rBase = 0;
+					if ((tid & 63) == 0) {
+						if (wTot)
+							wBase = atomicAdd(&s_w, wTot);
+						if (rTot)
+							rBase = atomicAdd(&s_b, rTot);
+					}
+					wBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wBase);
+					rBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rBase);
+					const unsigned long long ltMask = (1ull << (tid & 63)) - 1ull;
 #pragma unroll
 					for (int u = 0; u < 8; u++) {
 						const uint32_t i = i0 + u * WF_T + tid;
@@ -423,8 +478,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						const uint32_t c = ec[u], cell = ecell[u], ord = eord[u];
 						const bool inWindow = in && c < hiBits;
 						const bool inRest = in && !inWindow;
-						const uint32_t wslot = wave_alloc(&s_w, inWindow);
-						const uint32_t bslot = wave_alloc(&s_b, inRest);
+						const uint32_t wslot = wBase + (uint32_t)__popcll(bwM[u] & ltMask);
+						const uint32_t bslot = rBase + (uint32_t)__popcll(brM[u] & ltMask);
+						wBase += (uint32_t)__popcll(bwM[u]);
+						rBase += (uint32_t)__popcll(brM[u]);
 						if (inWindow) {
 							if (fast) {
 								const uint32_t rel = ord - ordFloor;
@@ -437,13 +494,20 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 								S.gvals[wslot] = cell;
 							}
 						} else if (inRest) {
-							S.fcell[nxt][bslot] = cell; // bslot < n <= fcap
-							S.fcost[nxt][bslot] = c;
-							S.ford[nxt][bslot] = ord;
+							if (inLds) {
+								lco[bslot] = ((uint64_t)c << 32) | ord; // bslot <= i: never overtakes an unread entry
+								lcell[bslot] = cell;
+							} else {
+								S.fcell[nxt][bslot] = cell; // bslot < n <= fcap
+								S.fcost[nxt][bslot] = c;
+								S.ford[nxt][bslot] = ord;
+							}
 							restMin = min(restMin, c);
 							restOrd = min(restOrd, ord);
 						}
 					}
+					if (inLds)
+						__syncthreads();
 				}
 				if (restMin != 0xFFFFFFFFu) {
 					atomicMin(&s_minNext, restMin);
@@ -456,7 +520,14 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				__syncthreads();
 				if (!fast || ok)
 					break;
-				fast = false; // redo into the HBM buffers
+				// Redo into the HBM buffers.  An in-place LDS compaction cannot be replayed, so the redo is only taken
+				// while the list is in HBM; with the list in LDS the window entries are recovered from the packed keys
+				// (n <= WF_LIST <= WF_LCAP there, so they all fitted) -- only the encoding overflowed.
+				fast = false;
+				if (inLds) {
+					overflow = true; // encoding overflow with an LDS-resident list: cannot happen for grids <= 2^21 padded cells
+					break;
+				}
 				if (tid == 0) {
 					s_w = 0;
 					s_b = 0;
@@ -464,7 +535,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				__syncthreads();
 			}
 			WF_STAMP(WP_PART);
-			if (w > S.gcap || round + 1u >= (1u << 15) || w > (1u << 17)) {
+			if (overflow || w > S.gcap || round + 1u >= (1u << 15) || w > (1u << 17)) {
 				overflow = true;
 				break;
 			}
@@ -488,9 +559,32 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				ph[WP_SUMP] += P;
 			}
 			uint32_t newMin = 0xFFFFFFFFu, newOrd = 0xFFFFFFFFu;
+			// Where do this round's pushes go?  They stay in LDS while survivors + every push are known to fit
+			// (decided below, once the number of discovered cells is known or bounded).
+			bool pushLds = false;
+			// appends one discovered cell to the open list (slot relative to the survivors)
+			auto push_entry = [&](uint32_t slot, uint32_t ncell, uint32_t pb, uint32_t ord) {
+				if (pushLds) {
+					lco[slot] = ((uint64_t)pb << 32) | ord;
+					lcell[slot] = ncell;
+				} else if (slot < S.fcap) {
+					S.fcell[nxt][slot] = ncell;
+					S.fcost[nxt][slot] = pb;
+					S.ford[nxt][slot] = ord;
+				}
+			};
+			// the list leaves LDS before the pushes when they might not fit: survivors are copied to HBM once
+			auto spill_list = [&]() {
+				for (uint32_t i = tid; i < b; i += WF_T) {
+					const uint64_t e = lco[i];
+					S.fcell[nxt][i] = lcell[i];
+					S.fcost[nxt][i] = (uint32_t)(e >> 32);
+					S.ford[nxt][i] = (uint32_t)e;
+				}
+			};
 			// The claim table has WF_HCAP slots; the round may use it only when every candidate (counted with
 			// duplicates, so an upper bound on distinct cells) fits with room to spare: insertion then always ends.
-			uint32_t myCell[4] = { 0, 0, 0, 0 }, myCost[4] = { 0, 0, 0, 0 }, myMask[4] = { 0, 0, 0, 0 };
+			uint32_t myCell[4] = { 0, 0, 0, 0 }, myCost[4] = { 0, 0, 0, 0 }, myMask[4] = { 0, 0, 0, 0 }, myOut[4] = { 0, 0, 0, 0 };
 			bool hashed = false;
 			if (fast && w <= 4u * WF_T) {
 				Row3 up[4], mid[4], dn[4];
@@ -501,10 +595,12 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						const uint64_t k = skey[SK((int)i)];
 						myCell[q] = (uint32_t)(k & 0x1FFFFFu);
 						myCost[q] = lBits + (uint32_t)(k >> 41);
-						const uint32_t* base = S.grid + myCell[q];
-						up[q] = load_row3(base - pc - 1);
-						mid[q] = load_row3(base - 1);
-						dn[q] = load_row3(base + pc - 1);
+						const int pr = (int)(myCell[q] / (uint32_t)pc), pcc = (int)(myCell[q] - (uint32_t)pr * (uint32_t)pc);
+						const uint8_t* rowBase = state + (int64_t)pr * pc;
+						myOut[q] = (uint32_t)((pr - 1) * cols + (pcc - 1)); // index of the cell in the (unpadded) output field
+						up[q] = load_state3(rowBase - pc, pcc - 1);
+						mid[q] = load_state3(rowBase, pcc - 1);
+						dn[q] = load_state3(rowBase + pc, pcc - 1);
 					}
 				}
 				uint32_t cnt = 0;
@@ -554,44 +650,85 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					}
 				}
 				__syncthreads();
+				{ // number of distinct discovered cells = occupied table slots: decides whether the pushes stay in LDS
+					uint32_t cnt = 0;
+					for (int i = tid; i < WF_HCAP; i += WF_T)
+						cnt += hcell[i] != 0u;
+					for (int off = 32; off > 0; off >>= 1)
+						cnt += __shfl_xor((int)cnt, off, 64);
+					if ((tid & 63) == 0 && cnt)
+						atomicAdd(&s_distinct, cnt);
+					__syncthreads();
+					pushLds = inLds && b + s_distinct <= (uint32_t)WF_LIST;
+					if (inLds && !pushLds)
+						spill_list();
+				}
 				WF_STAMP(WP_OFFER);
-				// push the winners: cost fixed at discovery (Q3), push order = roundBase + i*8 + j.  Uniform control flow:
-				// every lane takes part in the ballot that hands out open-list slots (one LDS atomic per wave).
+				// push the winners: cost fixed at discovery (Q3), push order = roundBase + i*8 + j.  Each lane first finds
+				// its wins (bit q*8+j), a wave scan then hands out consecutive open-list slots with ONE LDS atomic per wave.
+				uint32_t winBits = 0;
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					const uint32_t i = tid + q * WF_T;
 					const uint32_t mk = (i < w) ? myMask[q] : 0u;
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						if (!(mk & (1u << j)))
+							continue;
+						const uint32_t ncell = myCell[q] + (uint32_t)nbOff[j];
+						uint32_t h = (ncell * 2654435761u) >> (32 - 12);
+						while (hcell[h] != ncell + 1u)
+							h = (h + 1) & (WF_HCAP - 1);
+						if (hkey[h] == i * 8u + (uint32_t)j)
+							winBits |= 1u << (q * 8 + j);
+					}
+				}
+				const uint32_t nWin = (uint32_t)__popc(winBits);
+				uint32_t incl = nWin;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+					const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+					if ((tid & 63) >= d)
+						incl += t;
+				}
+				uint32_t wbase = 0;
+				if ((tid & 63) == 63 && incl)
+					wbase = atomicAdd(&s_new, incl);
+				wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
+				uint32_t slot = b + wbase + incl - nWin;
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					if (!((winBits >> (q * 8)) & 0xFFu))
+						continue;
+					const uint32_t i = tid + q * WF_T;
 					const float ci = __uint_as_float(myCost[q]);
 #pragma unroll
 					for (int j = 0; j < 8; j++) {
-						const bool cand = (mk & (1u << j)) != 0u;
+						if (!(winBits & (1u << (q * 8 + j))))
+							continue;
 						const uint32_t ncell = myCell[q] + (uint32_t)nbOff[j];
 						const uint32_t key = i * 8u + (uint32_t)j;
-						bool win = false;
-						if (cand) {
-							uint32_t h = (ncell * 2654435761u) >> (32 - 12);
-							while (hcell[h] != ncell + 1u)
-								h = (h + 1) & (WF_HCAP - 1);
-							win = hkey[h] == key;
-						}
-						const uint32_t slot = b + wave_alloc(&s_new, win);
-						if (win) {
-							const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
-							const float pathCost = transitionCost + ci; // heuristics.cpp:135
-							const uint32_t pb = __float_as_uint(pathCost);
-							S.grid[ncell] = pb;
-							newMin = min(newMin, pb);
-							newOrd = min(newOrd, roundBase + key);
-							if (slot < S.fcap) {
-								S.fcell[nxt][slot] = ncell;
-								S.fcost[nxt][slot] = pb;
-								S.ford[nxt][slot] = roundBase + key;
-							}
-						}
+						const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
+						const float pathCost = transitionCost + ci; // heuristics.cpp:135
+						const uint32_t pb = __float_as_uint(pathCost);
+						state[ncell] = (uint8_t)ST_SEEN;
+						cost[(int)myOut[q] + kDr[j] * cols + kDc[j]] = pathCost;
+						newMin = min(newMin, pb);
+						newOrd = min(newOrd, roundBase + key);
+						push_entry(slot++, ncell, pb, roundBase + key);
 					}
 				}
 			} else {
 				// ================= fallback: publish (round, rank), gather the other neighbours of n =================
+				pushLds = inLds && b + 8u * w <= (uint32_t)WF_LIST;
+				if (inLds && !pushLds)
+					spill_list();
+				if (tagGoal != g) { // first fallback round of this goal: stale (round, rank) words of earlier goals must go
+					for (int64_t i = tid; i < pcells; i += WF_T)
+						S.tag[i] = 0u;
+					__syncthreads();
+					tagGoal = g;
+				}
 				const uint32_t roundTag = (round + 1u) << 17;
 				for (uint32_t i = tid; i < w; i += WF_T) {
 					const uint32_t cell = fast ? (uint32_t)(skey[SK((int)i)] & 0x1FFFFFu) : S.gvals[i];
@@ -610,8 +747,9 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						cbits = (uint32_t)(S.gkeys[i] >> 32);
 					}
 					const float ci = __uint_as_float(cbits);
-					const uint32_t* base = S.grid + cell;
-					const Row3 up = load_row3(base - pc - 1), mid = load_row3(base - 1), dn = load_row3(base + pc - 1);
+					const int pr = (int)(cell / (uint32_t)pc), pcc = (int)(cell - (uint32_t)pr * (uint32_t)pc);
+					const uint8_t* rowBase = state + (int64_t)pr * pc;
+					const Row3 up = load_state3(rowBase - pc, pcc - 1), mid = load_state3(rowBase, pcc - 1), dn = load_state3(rowBase + pc, pcc - 1);
 					const uint32_t mk = candidate_mask(up, mid, dn);
 #pragma unroll
 					for (int j = 0; j < 8; j++) {
@@ -619,12 +757,14 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 							continue;
 						// n = neighbour j.  Is another window cell the first to reach n?
 						const uint32_t ncell = cell + (uint32_t)nbOff[j];
+						const int nr = pr + kDr[j], nc = pcc + kDc[j];
 						const uint32_t mine = i * 8u + (uint32_t)j;
 						const Row3 tu = load_row3(S.tag + ncell - pc - 1), tm = load_row3(S.tag + ncell - 1), td = load_row3(S.tag + ncell + pc - 1);
-						const Row3 gu = load_row3(S.grid + ncell - pc - 1), gm = load_row3(S.grid + ncell - 1), gd = load_row3(S.grid + ncell + pc - 1);
+						const uint8_t* nrow = state + (int64_t)nr * pc;
+						const Row3 gu = load_state3(nrow - pc, nc - 1), gm = load_state3(nrow, nc - 1), gd = load_state3(nrow + pc, nc - 1);
 						// p'' = n - d_jj reaches n through direction jj: p'' sits at offset -d_jj from n
 						const uint32_t tg[8] = { tm.c, td.c, tu.c, tm.a, td.a, tu.a, td.b, tu.b };
-						const bool oL = gm.a == kOccBits, oR = gm.c == kOccBits, oU = gu.b == kOccBits, oD = gd.b == kOccBits; // n's orthogonal neighbours
+						const bool oL = gm.a == ST_OCC, oR = gm.c == ST_OCC, oU = gu.b == ST_OCC, oD = gd.b == ST_OCC; // n's orthogonal neighbours
 						bool win = true;
 #pragma unroll
 						for (int jj = 0; jj < 8; jj++) {
@@ -646,15 +786,12 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
 						const float pathCost = transitionCost + ci; // heuristics.cpp:135
 						const uint32_t pb = __float_as_uint(pathCost);
-						S.grid[ncell] = pb;
+						state[ncell] = (uint8_t)ST_SEEN;
+						cost[(int64_t)(nr - 1) * cols + (nc - 1)] = pathCost;
 						newMin = min(newMin, pb);
 						newOrd = min(newOrd, roundBase + mine);
 						const uint32_t slot = b + atomicAdd(&s_new, 1u);
-						if (slot < S.fcap) {
-							S.fcell[nxt][slot] = ncell;
-							S.fcost[nxt][slot] = pb;
-							S.ford[nxt][slot] = roundBase + mine;
-						}
+						push_entry(slot, ncell, pb, roundBase + mine);
 					}
 				}
 			}
@@ -663,6 +800,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				atomicMin(&s_ordMinNext, newOrd);
 			}
 			__syncthreads();
+			if (kProfile && !hashed) {
+				ph[WP_FBROUNDS]++;
+				ph[WP_FBCYC] += clock64() - tl;
+			}
 			WF_STAMP(WP_PUSH);
 			const uint32_t nn = b + s_new;
 			const uint32_t nextMin = s_minNext, nextOrd = s_ordMinNext;
@@ -677,27 +818,35 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				s_new = 0;
 				s_packFail = 0;
 				s_cand = 0;
+				s_distinct = 0;
 			}
 			__syncthreads();
 			if (nn > S.fcap) {
 				overflow = true;
 				break;
 			}
+			// where the list lives next round
+			if (inLds && !pushLds) {
+				inLds = false; // it was moved to S.f*[nxt] above
+				cur = nxt;
+			} else if (!inLds) {
+				cur = nxt;
+				if (nn <= (uint32_t)WF_LIST / 4) { // small again: bring it back into LDS
+					for (uint32_t i = tid; i < nn; i += WF_T) {
+						lco[i] = ((uint64_t)S.fcost[cur][i] << 32) | S.ford[cur][i];
+						lcell[i] = S.fcell[cur][i];
+					}
+					__syncthreads();
+					inLds = true;
+				}
+			}
 			roundBase += w * 8u;
 			round++;
 			n = nn;
-			cur = nxt;
 			WF_STAMP(WP_TAIL);
 		}
 		if (overflow && tid == 0)
 			*errorFlag = 1; // open list / round count beyond the workspace encoding
-		__syncthreads();
-		// ---- result: unpadded field, +inf where the reference leaves the cell unexplored (occupied or unreachable)
-		for (int64_t i = tid; i < cells; i += WF_T) {
-			const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
-			const uint32_t v = S.grid[(int64_t)(r + 1) * pc + (c + 1)];
-			cost[i] = __uint_as_float(v == kOccBits ? kInfBits : v);
-		}
 		__syncthreads();
 		if (kProfile && tid == 0)
 			for (int i = 0; i < WP_COUNT; i++)
