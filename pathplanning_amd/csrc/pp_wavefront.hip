@@ -39,34 +39,29 @@ constexpr uint32_t kInfBits = 0x7F800000u;
 constexpr uint32_t kOccBits = 0x7FC00000u; // NaN pattern marking occupied / border cells in the working grid
 
 struct WfSlot {
-	uint32_t* grid;      // [(rows+2)*(cols+2)] working costs (padded)
-	uint32_t* tag;       // [(rows+2)*(cols+2)] (round+1) << 17 | rank, fallback claim resolution
-	uint32_t* fcell[2];  // open list ping-pong, [fcap]: padded cell index
-	uint32_t* fcost[2];
-	uint32_t* ford[2];
+	uint8_t* state;      // [(rows+2) * pc] one byte per padded cell: free / occupied (and border) / discovered
+	uint32_t* tag;       // [(rows+2) * pc] (round+1) << 17 | rank, fallback claim resolution
+	uint64_t* fent[2];   // open list in HBM (ping-pong), [fcap]: cost bits << 32 | padded cell, in push order
 	uint64_t* gkeys;     // fallback sort buffers in HBM, [gcap] (gcap = pow2 >= fcap)
 	uint32_t* gvals;
 	uint32_t fcap, gcap;
 };
 
-__host__ __device__ inline int64_t padded_cells(int rows, int cols) { return (int64_t)(rows + 2) * ((cols + 2 + 7) & ~7); }
+__host__ __device__ inline int padded_stride(int cols) { return (cols + 2 + 7) & ~7; }
+__host__ __device__ inline int64_t padded_cells(int rows, int cols) { return (int64_t)(rows + 2) * padded_stride(cols); }
+__host__ __device__ inline int64_t round256(int64_t b) { return (b + 255) / 256 * 256; }
 
 __device__ __forceinline__ WfSlot slot_view(void* base, int64_t bytesPerSlot, int slot, int64_t pcells, uint32_t fcap, uint32_t gcap)
 {
 	char* p = (char*)base + (int64_t)slot * bytesPerSlot;
 	WfSlot s;
-	const int64_t gbytes = (pcells * 4 + 255) / 256 * 256;
-	s.grid = (uint32_t*)p;
-	p += gbytes;
+	s.state = (uint8_t*)p;
+	p += round256(pcells + 16); // row loads may run a few bytes past the last row
 	s.tag = (uint32_t*)p;
-	p += gbytes;
+	p += round256(pcells * 4 + 16);
 	for (int k = 0; k < 2; k++) {
-		s.fcell[k] = (uint32_t*)p;
-		p += (int64_t)fcap * 4;
-		s.fcost[k] = (uint32_t*)p;
-		p += (int64_t)fcap * 4;
-		s.ford[k] = (uint32_t*)p;
-		p += (int64_t)fcap * 4;
+		s.fent[k] = (uint64_t*)p;
+		p += (int64_t)fcap * 8;
 	}
 	s.gkeys = (uint64_t*)p;
 	p += (int64_t)gcap * 8;
@@ -316,7 +311,123 @@ __device__ __forceinline__ uint32_t candidate_mask(const Row3& up, const Row3& m
 // kProfile: diagnostic build -- per goal {init, min, partition, sort, offer, push, tail} shader-clock sums + rounds, sum(w), sum(P)
 enum { WP_INIT = 0, WP_MIN, WP_PART, WP_SORT, WP_OFFER, WP_PUSH, WP_TAIL, WP_ROUNDS, WP_SUMW, WP_SUMP, WP_FBROUNDS, WP_FBCYC, WP_COUNT };
 
-constexpr int WF_LIST = 3072; // open-list entries kept in LDS (36 KiB); beyond that the list lives in HBM
+constexpr int WF_LIST = 4096; // open-list entries kept in LDS (32 KiB); beyond that the list lives in HBM
+constexpr int WF_NB = 2048;   // buckets of the rank sort
+constexpr int WF_W = WF_T / 64;
+
+/// workgroup barrier that orders LDS traffic only: global stores in flight are NOT waited for (a __syncthreads()
+/// drains vmcnt, i.e. costs a full memory round trip whenever scattered stores are pending)
+__device__ __forceinline__ void lds_barrier()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+/// inclusive prefix sum over the 64 lanes of a wave in DPP steps (no LDS): Hillis-Steele inside each row of 16,
+/// then the row totals are carried across with row_bcast15 / row_bcast31
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
+{
+	uint32_t x = v;
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false); // row_shr:1
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false); // row_shr:2
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false); // row_shr:4
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false); // row_shr:8
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false); // row_bcast15 -> rows 1, 3
+	x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false); // row_bcast31 -> rows 2, 3
+	return x;
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+	const int id = (int)0xFFFFFFFF;
+	uint32_t x = v;
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x111, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x112, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x114, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x118, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x142, 0xA, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x143, 0xC, 0xF, false));
+	return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+/// Rank sort of the w <= 4096 packed window keys in skey (ascending), whole block.  The bitonic network needs
+/// ~20 dependent LDS round trips; here the keys are bucketed on the leading bits of (cost - L) with an LDS
+/// histogram (the atomic's return value is the arrival index inside the bucket), a block scan turns the
+/// histogram into bucket offsets, and only members of the same bucket are compared with each other (equal costs
+/// are common -- symmetric cells -- so buckets hold a handful of keys).  Seven barriers, all LDS-only.
+/// hist must be all zero on entry and is all zero again on exit.
+__device__ __forceinline__ void rank_sort(uint64_t* skey, uint32_t* hist, uint32_t* wsum, uint32_t w, uint32_t range)
+{
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int bitsRange = range > 1u ? 32 - __clz((int)(range - 1u)) : 0;
+	const int shift = bitsRange > 11 ? bitsRange - 11 : 0; // (cost - L) >> shift < WF_NB
+	uint64_t k[8];
+	uint32_t meta[8];
+#pragma unroll
+	for (int u = 0; u < 8; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		k[u] = i < w ? skey[SK((int)i)] : ~0ull;
+	}
+	lds_barrier();
+#pragma unroll
+	for (int u = 0; u < 8; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		if (i < w) {
+			const uint32_t bkt = (uint32_t)(k[u] >> 41) >> shift;
+			const uint32_t arr = atomicAdd(&hist[bkt], 1u);
+			meta[u] = bkt | (arr << 11);
+		}
+	}
+	lds_barrier();
+	// exclusive scan of the histogram: 4 consecutive buckets per thread
+	uint4 h = reinterpret_cast<uint4*>(hist)[tid];
+	const uint32_t s0 = h.x, s1 = s0 + h.y, s2 = s1 + h.z, s3 = s2 + h.w;
+	const uint32_t incl = wave_incl_add(s3);
+	if (lane == 63)
+		wsum[wave] = incl;
+	lds_barrier();
+	uint32_t base = incl - s3;
+#pragma unroll
+	for (int v = 0; v < WF_W; v++)
+		base += v < wave ? wsum[v] : 0u;
+	reinterpret_cast<uint4*>(hist)[tid] = make_uint4(base, base + s0, base + s1, base + s2);
+	lds_barrier();
+	bool multi = false;
+#pragma unroll
+	for (int u = 0; u < 8; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		if (i < w) {
+			const uint32_t bkt = meta[u] & (WF_NB - 1), arr = meta[u] >> 11;
+			const uint32_t st = hist[bkt], en = bkt + 1 < (uint32_t)WF_NB ? hist[bkt + 1] : w;
+			skey[SK((int)(st + arr))] = k[u];
+			meta[u] = st | ((en - st) << 12);
+			multi = multi || en - st > 1u;
+		}
+	}
+	lds_barrier();
+	reinterpret_cast<uint4*>(hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+	for (int u = 0; u < 8; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		if (i < w) {
+			const uint32_t st = meta[u] & 0xFFFu, size = meta[u] >> 12;
+			uint32_t rank = st;
+			if (size > 1u)
+				for (uint32_t p = st; p < st + size; p++)
+					rank += skey[SK((int)p)] < k[u];
+			meta[u] = rank;
+		}
+	}
+	lds_barrier();
+#pragma unroll
+	for (int u = 0; u < 8; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		if (i < w && multi) // a lane whose buckets are all singletons already sits at its rank
+			skey[SK((int)meta[u])] = k[u];
+	}
+	lds_barrier();
+}
 
 #ifndef PP_WF_WAVES_PER_SIMD
 #define PP_WF_WAVES_PER_SIMD 4 // 2 workgroups of 8 waves per CU: <= 128 VGPRs
@@ -333,24 +444,32 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		ph[i] += now_ - tl;                        \
 		tl = now_;                                 \
 	}
-	__shared__ uint64_t skey[kSkewed(WF_LCAP)]; // sort buffer (skewed layout), then (as two uint32 arrays) the claim hash table
-	__shared__ uint64_t lco[WF_LIST];            // open list in LDS: cost bits << 32 | push order
-	__shared__ uint32_t lcell[WF_LIST];          //                   padded cell index
-	__shared__ uint32_t s_min, s_minNext, s_ordMin, s_ordMinNext, s_w, s_b, s_new, s_packFail, s_cand, s_distinct;
+	__shared__ uint64_t skey[kSkewed(WF_LCAP)]; // window keys (skewed layout), then (as two uint32 arrays) the claim hash table
+	__shared__ uint64_t lent[WF_LIST];           // open list in LDS, in push order: cost bits << 32 | padded cell
+	__shared__ __attribute__((aligned(16))) uint32_t hist[WF_NB];
+	__shared__ uint32_t s_wcnt[64];              // ordered compaction: counts per (chunk row u, wave)
+	__shared__ uint64_t s_wtot[WF_W];
+	__shared__ uint32_t s_wsum[WF_W];
+	__shared__ uint32_t s_min, s_minNext[2], s_packFail, s_cand;
 	__shared__ int s_goal;
 	uint32_t* const hcell = reinterpret_cast<uint32_t*>(skey);          // [WF_HCAP] padded cell index + 1, 0 = empty
 	uint32_t* const hkey = reinterpret_cast<uint32_t*>(skey) + WF_HCAP; // [WF_HCAP] min (i*8+j)
 
-	const int tid = threadIdx.x;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const unsigned long long ltMask = (1ull << lane) - 1ull;
 	const int cols = m.cols, rows = m.rows;
-	const int pc = (cols + 2 + 7) & ~7; // padded row stride of the state grid (bytes), multiple of 8
+	const int pc = padded_stride(cols); // padded row stride of the state grid (bytes), multiple of 8
 	const int64_t cells = (int64_t)rows * cols;
 	const int64_t pcells = (int64_t)(rows + 2) * pc;
+	const bool packable = pcells <= (1 << 21); // cell index fits the packed window key
 	WfSlot S = slot_view(workspace, bytesPerSlot, blockIdx.x, pcells, fcap, gcap);
-	uint8_t* const state = reinterpret_cast<uint8_t*>(S.grid); // [(rows+2) * pc] bytes
+	uint8_t* const state = S.state;
 	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
 	const int nbOff[8] = { -1, -pc - 1, pc - 1, 1, -pc + 1, pc + 1, -pc, pc }; // padded-index offsets of kDr/kDc
 
+	for (int i = tid; i < WF_NB; i += WF_T)
+		hist[i] = 0u;
 	int tagGoal = -1; // goal whose fallback rounds the tag grid currently describes (it is cleared lazily)
 	// goals are handed out dynamically: a workgroup that finishes early takes the next one (balanced tail)
 	for (;;) {
@@ -383,170 +502,157 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		const int32_t start = goalCells[g];
 		if (tid == 0) {
 			s_min = 0u; // cost bits of the start cell
-			s_minNext = 0xFFFFFFFFu;
-			s_ordMin = 0u;
-			s_ordMinNext = 0xFFFFFFFFu;
-			s_w = 0;
-			s_b = 0;
-			s_new = 0;
+			s_minNext[0] = 0xFFFFFFFFu;
+			s_minNext[1] = 0xFFFFFFFFu;
 			s_packFail = 0;
 			s_cand = 0;
-			s_distinct = 0;
 		}
 		__syncthreads();
 		if (start < 0)
 			continue; // goal outside the map (heuristics.cpp:115-117): the field stays +inf
+		bool inLds = packable; // where the open list lives
+		int cur = 0;           // ping-pong index of the HBM list
 		if (tid == 0) {
 			const int sr = start / cols, sc = start - sr * cols;
 			const uint32_t sp = (uint32_t)((sr + 1) * pc + (sc + 1));
 			state[sp] = (uint8_t)ST_SEEN; // the reference pushes the goal cell even when it is occupied
 			cost[start] = 0.0f;
-			lco[0] = 0ull; // cost 0, order 0
-			lcell[0] = sp;
+			if (inLds)
+				lent[0] = (uint64_t)sp; // cost 0
+			else
+				S.fent[0][0] = (uint64_t)sp;
 		}
 		__syncthreads();
 
 		WF_STAMP(WP_INIT);
-		uint32_t n = 1;         // open-list size
-		uint32_t roundBase = 1; // next push-order value
+		uint32_t n = 1; // open-list size
 		uint32_t round = 0;
-		bool inLds = true;      // where the open list lives
-		int cur = 0;            // ping-pong index of the HBM list
+		uint32_t lBits = 0u; // smallest cost in the open list
 		bool overflow = false;
 
 		while (n > 0) {
 			const int nxt = cur ^ 1;
-			// ---- L = smallest cost in the open list (tracked while the list was written in the previous round)
-			const uint32_t lBits = s_min;
+			const int par = (int)(round & 1u);
 			const float L = __uint_as_float(lBits);
 			const uint32_t hiBits = __float_as_uint(L + 1.0f);
-			const uint32_t ordFloor = s_ordMin;
 			WF_STAMP(WP_MIN);
-			// ---- partition: window (cost < fl(L+1)) -> sort buffer; the rest stays in the open list.
-			// Window entries are packed as (cost - L : 23 | ~(order - floor) : 20 | cell : 21) in LDS; when a round does
-			// not fit that encoding (or the LDS buffer) the window goes to the unpacked HBM buffers instead.
-			const bool packable = pcells <= (1 << 21);
+			// ---- partition: window (cost < fl(L+1)) -> sort buffer; the rest stays in the open list IN ORDER.
+			// The list is kept in push order, so "pushed later" == "further back": a window entry is packed as
+			// (cost - L : 23 | ~position : 20 | cell : 21) and sorting those keys yields the reference's pop order
+			// (cost ascending, most recent push first).  Slots come from ballots + one 64-entry scan per chunk.
 			bool fast = true;
 			uint32_t w = 0, b = 0;
-			for (int attempt = 0; attempt < 2; attempt++) {
-				uint32_t restMin = 0xFFFFFFFFu, restOrd = 0xFFFFFFFFu;
-				for (uint32_t i0 = 0; i0 < n; i0 += 8 * WF_T) {
-					// up to 8 entries per thread are read before any is written back (in-place compaction of the LDS list)
-					uint32_t ec[8], ecell[8], eord[8];
+			uint32_t restMin = 0xFFFFFFFFu;
+			if (inLds) {
+				uint64_t e[8];
+				unsigned long long bw[8], br[8];
 #pragma unroll
-					for (int u = 0; u < 8; u++) {
-						const uint32_t i = i0 + u * WF_T + tid;
-						const bool in = i < n;
-						if (inLds) {
-							const uint64_t e = in ? lco[i] : ~0ull;
-							ec[u] = (uint32_t)(e >> 32);
-							eord[u] = (uint32_t)e;
-							ecell[u] = in ? lcell[i] : 0u;
-						} else {
-							ec[u] = in ? S.fcost[cur][i] : 0xFFFFFFFFu;
-							ecell[u] = in ? S.fcell[cur][i] : 0u;
-							eord[u] = in ? S.ford[cur][i] : 0u;
+				for (int u = 0; u < 8; u++) {
+					const uint32_t i = (uint32_t)(u * WF_T + tid);
+					e[u] = i < n ? lent[i] : ~0ull;
+					const bool inW = i < n && (uint32_t)(e[u] >> 32) < hiBits;
+					bw[u] = __ballot(inW);
+					br[u] = __ballot(i < n && !inW);
+					if (lane == 0)
+						s_wcnt[u * WF_W + wave] = ((uint32_t)__popcll(bw[u]) << 16) | (uint32_t)__popcll(br[u]);
+				}
+				lds_barrier(); // counts visible; every entry read before the list is compacted in place
+				const uint32_t cnt = s_wcnt[lane];
+				const uint32_t incl = wave_incl_add(cnt);
+				const uint32_t excl = incl - cnt;
+				const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+				w = total >> 16;
+				b = total & 0xFFFFu;
+#pragma unroll
+				for (int u = 0; u < 8; u++) {
+					const uint32_t i = (uint32_t)(u * WF_T + tid);
+					const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)excl, u * WF_W + wave);
+					const uint32_t c = (uint32_t)(e[u] >> 32), cell = (uint32_t)e[u];
+					const bool inW = i < n && c < hiBits;
+					if (inW) {
+						const uint32_t wslot = (off >> 16) + (uint32_t)__popcll(bw[u] & ltMask);
+						skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0xFFFFFu - i) << 21) | (uint64_t)cell;
+					} else if (i < n) {
+						const uint32_t rslot = (off & 0xFFFFu) + (uint32_t)__popcll(br[u] & ltMask);
+						lent[rslot] = e[u];
+						restMin = min(restMin, c);
+					}
+				}
+			} else {
+				for (int attempt = 0; attempt < 2; attempt++) {
+					uint32_t wRun = 0, bRun = 0;
+					restMin = 0xFFFFFFFFu;
+					for (uint32_t i0 = 0; i0 < n; i0 += 8 * WF_T) {
+						uint64_t e[8];
+						unsigned long long bw[8], br[8];
+#pragma unroll
+						for (int u = 0; u < 8; u++) {
+							const uint32_t i = i0 + (uint32_t)(u * WF_T + tid);
+							e[u] = i < n ? S.fent[cur][i] : ~0ull;
+							const bool inW = i < n && (uint32_t)(e[u] >> 32) < hiBits;
+							bw[u] = __ballot(inW);
+							br[u] = __ballot(i < n && !inW);
+							if (lane == 0)
+								s_wcnt[u * WF_W + wave] = ((uint32_t)__popcll(bw[u]) << 16) | (uint32_t)__popcll(br[u]);
 						}
-					}
-					if (inLds)
-						__syncthreads(); // all reads of this chunk done before survivors are compacted over it
-					// one pair of LDS atomics per wave and chunk: ballots first, then the slots follow from lane prefixes
-					unsigned long long bwM[8], brM[8];
-					uint32_t wTot = 0, rTot = 0;
+						lds_barrier();
+						const uint32_t cnt = s_wcnt[lane];
+						const uint32_t incl = wave_incl_add(cnt);
+						const uint32_t excl = incl - cnt;
+						const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 #pragma unroll
-					for (int u = 0; u < 8; u++) {
-						const bool in = i0 + u * WF_T + tid < n;
-						bwM[u] = __ballot(in && ec[u] < hiBits);
-						brM[u] = __ballot(in && !(ec[u] < hiBits));
-						wTot += (uint32_t)__popcll(bwM[u]);
-						rTot += (uint32_t)__popcll(brM[u]);
-					}
-					uint32_t wBase = 0, rBase = 0;
-					if ((tid & 63) == 0) {
-						if (wTot)
-							wBase = atomicAdd(&s_w, wTot);
-						if (rTot)
-							rBase = atomicAdd(&s_b, rTot);
-					}
-					wBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wBase);
-					rBase = (uint32_t)__builtin_amdgcn_readfirstlane((int)rBase);
-					const unsigned long long ltMask = (1ull << (tid & 63)) - 1ull;
-#pragma unroll
-					for (int u = 0; u < 8; u++) {
-						const uint32_t i = i0 + u * WF_T + tid;
-						const bool in = i < n;
-						const uint32_t c = ec[u], cell = ecell[u], ord = eord[u];
-						const bool inWindow = in && c < hiBits;
-						const bool inRest = in && !inWindow;
-						const uint32_t wslot = wBase + (uint32_t)__popcll(bwM[u] & ltMask);
-						const uint32_t bslot = rBase + (uint32_t)__popcll(brM[u] & ltMask);
-						wBase += (uint32_t)__popcll(bwM[u]);
-						rBase += (uint32_t)__popcll(brM[u]);
-						if (inWindow) {
-							if (fast) {
-								const uint32_t rel = ord - ordFloor;
-								if (!packable || rel >= (1u << 20) || (c - lBits) >= (1u << 23))
-									s_packFail = 1;
-								if (wslot < WF_LCAP)
-									skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0xFFFFFu - (rel & 0xFFFFFu)) << 21) | (uint64_t)cell;
-							} else if (wslot < S.gcap) {
-								S.gkeys[wslot] = ((uint64_t)c << 32) | (uint64_t)(0xFFFFFFFFu - ord);
-								S.gvals[wslot] = cell;
+						for (int u = 0; u < 8; u++) {
+							const uint32_t i = i0 + (uint32_t)(u * WF_T + tid);
+							const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)excl, u * WF_W + wave);
+							const uint32_t c = (uint32_t)(e[u] >> 32), cell = (uint32_t)e[u];
+							const bool inW = i < n && c < hiBits;
+							if (inW) {
+								const uint32_t wslot = wRun + (off >> 16) + (uint32_t)__popcll(bw[u] & ltMask);
+								if (fast) {
+									if (!packable || i >= (1u << 20) || (c - lBits) >= (1u << 23))
+										s_packFail = 1;
+									if (wslot < (uint32_t)WF_LCAP)
+										skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0xFFFFFu - (i & 0xFFFFFu)) << 21) | (uint64_t)(cell & 0x1FFFFFu);
+								} else if (wslot < S.gcap) {
+									S.gkeys[wslot] = ((uint64_t)c << 32) | (uint64_t)(0xFFFFFFFFu - i);
+									S.gvals[wslot] = cell;
+								}
+							} else if (i < n) {
+								const uint32_t rslot = bRun + (off & 0xFFFFu) + (uint32_t)__popcll(br[u] & ltMask);
+								S.fent[nxt][rslot] = e[u]; // rslot < n <= fcap
+								restMin = min(restMin, c);
 							}
-						} else if (inRest) {
-							if (inLds) {
-								lco[bslot] = ((uint64_t)c << 32) | ord; // bslot <= i: never overtakes an unread entry
-								lcell[bslot] = cell;
-							} else {
-								S.fcell[nxt][bslot] = cell; // bslot < n <= fcap
-								S.fcost[nxt][bslot] = c;
-								S.ford[nxt][bslot] = ord;
-							}
-							restMin = min(restMin, c);
-							restOrd = min(restOrd, ord);
 						}
+						wRun += total >> 16;
+						bRun += total & 0xFFFFu;
+						lds_barrier(); // s_wcnt is rewritten by the next chunk
 					}
-					if (inLds)
-						__syncthreads();
+					w = wRun;
+					b = bRun;
+					lds_barrier();
+					const bool ok = !s_packFail && w <= (uint32_t)WF_LCAP;
+					if (!fast || ok)
+						break;
+					fast = false; // redo into the unpacked HBM buffers (the source list S.fent[cur] is untouched)
 				}
-				if (restMin != 0xFFFFFFFFu) {
-					atomicMin(&s_minNext, restMin);
-					atomicMin(&s_ordMinNext, restOrd);
-				}
-				__syncthreads();
-				w = s_w;
-				b = s_b;
-				const bool ok = !s_packFail && w <= WF_LCAP;
-				__syncthreads();
-				if (!fast || ok)
-					break;
-				// Redo into the HBM buffers.  An in-place LDS compaction cannot be replayed, so the redo is only taken
-				// while the list is in HBM; with the list in LDS the window entries are recovered from the packed keys
-				// (n <= WF_LIST <= WF_LCAP there, so they all fitted) -- only the encoding overflowed.
-				fast = false;
-				if (inLds) {
-					overflow = true; // encoding overflow with an LDS-resident list: cannot happen for grids <= 2^21 padded cells
-					break;
-				}
-				if (tid == 0) {
-					s_w = 0;
-					s_b = 0;
-				}
-				__syncthreads();
 			}
+			restMin = wave_min(restMin);
+			if (lane == 0 && restMin != 0xFFFFFFFFu)
+				atomicMin(&s_minNext[par], restMin);
+			if (tid == 0)
+				s_cand = 0;
+			lds_barrier();
 			WF_STAMP(WP_PART);
-			if (overflow || w > S.gcap || round + 1u >= (1u << 15) || w > (1u << 17)) {
+			if (w > S.gcap || round + 1u >= (1u << 15) || w > (1u << 17)) {
 				overflow = true;
 				break;
 			}
-			const uint32_t P = w <= 1 ? 2 : (1u << (32 - __clz((int)(w - 1))));
 			if (fast) {
-				for (uint32_t i = w + tid; i < (P < 8 ? 8u : P); i += WF_T)
-					skey[SK((int)i)] = ~0ull;
-				__syncthreads();
 				if (w > 1)
-					bitonic_sort_packed(skey, (int)(P < 8 ? 8 : P));
+					rank_sort(skey, hist, s_wsum, w, hiBits - lBits);
 			} else {
+				const uint32_t P = w <= 1 ? 2 : (1u << (32 - __clz((int)(w - 1))));
+				__syncthreads();
 				for (uint32_t i = w + tid; i < P; i += WF_T)
 					S.gkeys[i] = ~0ull;
 				__syncthreads();
@@ -556,38 +662,27 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			if (kProfile) {
 				ph[WP_ROUNDS]++;
 				ph[WP_SUMW] += w;
-				ph[WP_SUMP] += P;
+				ph[WP_SUMP] += w;
 			}
-			uint32_t newMin = 0xFFFFFFFFu, newOrd = 0xFFFFFFFFu;
-			// Where do this round's pushes go?  They stay in LDS while survivors + every push are known to fit
-			// (decided below, once the number of discovered cells is known or bounded).
+			uint32_t newMin = 0xFFFFFFFFu;
+			uint32_t newCount = 0;
+			// Where do this round's pushes go?  They stay in LDS while survivors + pushes fit (decided once the
+			// number of discovered cells is known or bounded).
 			bool pushLds = false;
-			// appends one discovered cell to the open list (slot relative to the survivors)
-			auto push_entry = [&](uint32_t slot, uint32_t ncell, uint32_t pb, uint32_t ord) {
-				if (pushLds) {
-					lco[slot] = ((uint64_t)pb << 32) | ord;
-					lcell[slot] = ncell;
-				} else if (slot < S.fcap) {
-					S.fcell[nxt][slot] = ncell;
-					S.fcost[nxt][slot] = pb;
-					S.ford[nxt][slot] = ord;
-				}
+			auto push_entry = [&](uint32_t slot, uint32_t ncell, uint32_t pb) {
+				if (pushLds)
+					lent[slot] = ((uint64_t)pb << 32) | ncell;
+				else if (slot < S.fcap)
+					S.fent[nxt][slot] = ((uint64_t)pb << 32) | ncell;
 			};
 			// the list leaves LDS before the pushes when they might not fit: survivors are copied to HBM once
 			auto spill_list = [&]() {
-				for (uint32_t i = tid; i < b; i += WF_T) {
-					const uint64_t e = lco[i];
-					S.fcell[nxt][i] = lcell[i];
-					S.fcost[nxt][i] = (uint32_t)(e >> 32);
-					S.ford[nxt][i] = (uint32_t)e;
-				}
+				for (uint32_t i = tid; i < b; i += WF_T)
+					S.fent[nxt][i] = lent[i];
 			};
-			// The claim table has WF_HCAP slots; the round may use it only when every candidate (counted with
-			// duplicates, so an upper bound on distinct cells) fits with room to spare: insertion then always ends.
 			uint32_t myCell[4] = { 0, 0, 0, 0 }, myCost[4] = { 0, 0, 0, 0 }, myMask[4] = { 0, 0, 0, 0 }, myOut[4] = { 0, 0, 0, 0 };
 			bool hashed = false;
 			if (fast && w <= 4u * WF_T) {
-				Row3 up[4], mid[4], dn[4];
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					const uint32_t i = tid + q * WF_T;
@@ -595,6 +690,14 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						const uint64_t k = skey[SK((int)i)];
 						myCell[q] = (uint32_t)(k & 0x1FFFFFu);
 						myCost[q] = lBits + (uint32_t)(k >> 41);
+					}
+				}
+				__syncthreads(); // the state bytes stored by the previous round are visible from here on
+				Row3 up[4], mid[4], dn[4];
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					const uint32_t i = tid + q * WF_T;
+					if (i < w) {
 						const int pr = (int)(myCell[q] / (uint32_t)pc), pcc = (int)(myCell[q] - (uint32_t)pr * (uint32_t)pc);
 						const uint8_t* rowBase = state + (int64_t)pr * pc;
 						myOut[q] = (uint32_t)((pr - 1) * cols + (pcc - 1)); // index of the cell in the (unpadded) output field
@@ -612,20 +715,23 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						cnt += __popc(myMask[q]);
 					}
 				}
-				for (int off = 32; off > 0; off >>= 1)
-					cnt += __shfl_xor((int)cnt, off, 64);
-				if ((tid & 63) == 0 && cnt)
+				cnt = wave_incl_add(cnt);
+				if (lane == 63 && cnt)
 					atomicAdd(&s_cand, cnt);
-				__syncthreads();
+				lds_barrier();
+				// The claim table has WF_HCAP slots; the round may use it only when every candidate (counted with
+				// duplicates, so an upper bound on distinct cells) fits with room to spare: insertion then always ends.
 				hashed = s_cand <= (uint32_t)(WF_HCAP * 3 / 4);
+			} else {
+				__syncthreads();
 			}
 			if (hashed) {
 				// ================= fast path: claims in an LDS hash table (the sort buffer is reused) =================
-				for (int i = tid; i < WF_HCAP; i += WF_T) {
-					hcell[i] = 0u;
-					hkey[i] = 0xFFFFFFFFu;
+				for (int i = tid; i < WF_HCAP / 4; i += WF_T) {
+					reinterpret_cast<uint4*>(hcell)[i] = make_uint4(0u, 0u, 0u, 0u);
+					reinterpret_cast<uint4*>(hkey)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
 				}
-				__syncthreads();
+				lds_barrier();
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					const uint32_t i = tid + q * WF_T;
@@ -649,23 +755,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						}
 					}
 				}
-				__syncthreads();
-				{ // number of distinct discovered cells = occupied table slots: decides whether the pushes stay in LDS
-					uint32_t cnt = 0;
-					for (int i = tid; i < WF_HCAP; i += WF_T)
-						cnt += hcell[i] != 0u;
-					for (int off = 32; off > 0; off >>= 1)
-						cnt += __shfl_xor((int)cnt, off, 64);
-					if ((tid & 63) == 0 && cnt)
-						atomicAdd(&s_distinct, cnt);
-					__syncthreads();
-					pushLds = inLds && b + s_distinct <= (uint32_t)WF_LIST;
-					if (inLds && !pushLds)
-						spill_list();
-				}
+				lds_barrier();
 				WF_STAMP(WP_OFFER);
-				// push the winners: cost fixed at discovery (Q3), push order = roundBase + i*8 + j.  Each lane first finds
-				// its wins (bit q*8+j), a wave scan then hands out consecutive open-list slots with ONE LDS atomic per wave.
+				// the winners: a lane first finds its wins (bit q*8+j); a block scan then hands out open-list slots in
+				// the reference's push order, i.e. ascending (i, j) = ascending (q, thread, j)
 				uint32_t winBits = 0;
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
@@ -683,39 +776,50 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 							winBits |= 1u << (q * 8 + j);
 					}
 				}
-				const uint32_t nWin = (uint32_t)__popc(winBits);
-				uint32_t incl = nWin;
+				// per-q counts packed in 16-bit fields (a field never exceeds 4096)
+				const uint32_t c01 = (uint32_t)__popc(winBits & 0xFFu) | ((uint32_t)__popc(winBits & 0xFF00u) << 16);
+				const uint32_t c23 = (uint32_t)__popc(winBits & 0xFF0000u) | ((uint32_t)__popc(winBits & 0xFF000000u) << 16);
+				const uint32_t i01 = wave_incl_add(c01), i23 = wave_incl_add(c23);
+				if (lane == 63)
+					s_wtot[wave] = ((uint64_t)i23 << 32) | i01;
+				lds_barrier();
+				uint64_t all = 0, pre = 0;
 #pragma unroll
-				for (int d = 1; d < 64; d <<= 1) {
-					const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
-					if ((tid & 63) >= d)
-						incl += t;
+				for (int v = 0; v < WF_W; v++) {
+					const uint64_t t = s_wtot[v];
+					all += t;
+					pre += v < wave ? t : 0ull;
 				}
-				uint32_t wbase = 0;
-				if ((tid & 63) == 63 && incl)
-					wbase = atomicAdd(&s_new, incl);
-				wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
-				uint32_t slot = b + wbase + incl - nWin;
+				const uint64_t exclT = pre + (((uint64_t)(i23 - c23) << 32) | (uint64_t)(i01 - c01)); // per-q exclusive prefix of this lane
+				uint32_t qBase[4];
+				uint32_t run = 0;
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					qBase[q] = b + run + (uint32_t)((exclT >> (16 * q)) & 0xFFFFu);
+					run += (uint32_t)((all >> (16 * q)) & 0xFFFFu);
+				}
+				newCount = run;
+				pushLds = inLds && b + newCount <= (uint32_t)WF_LIST;
+				if (inLds && !pushLds)
+					spill_list();
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					if (!((winBits >> (q * 8)) & 0xFFu))
 						continue;
-					const uint32_t i = tid + q * WF_T;
 					const float ci = __uint_as_float(myCost[q]);
+					uint32_t slot = qBase[q];
 #pragma unroll
 					for (int j = 0; j < 8; j++) {
 						if (!(winBits & (1u << (q * 8 + j))))
 							continue;
 						const uint32_t ncell = myCell[q] + (uint32_t)nbOff[j];
-						const uint32_t key = i * 8u + (uint32_t)j;
 						const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
 						const float pathCost = transitionCost + ci; // heuristics.cpp:135
 						const uint32_t pb = __float_as_uint(pathCost);
 						state[ncell] = (uint8_t)ST_SEEN;
 						cost[(int)myOut[q] + kDr[j] * cols + kDc[j]] = pathCost;
 						newMin = min(newMin, pb);
-						newOrd = min(newOrd, roundBase + key);
-						push_entry(slot++, ncell, pb, roundBase + key);
+						push_entry(slot++, ncell, pb);
 					}
 				}
 			} else {
@@ -726,9 +830,9 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				if (tagGoal != g) { // first fallback round of this goal: stale (round, rank) words of earlier goals must go
 					for (int64_t i = tid; i < pcells; i += WF_T)
 						S.tag[i] = 0u;
-					__syncthreads();
 					tagGoal = g;
 				}
+				__syncthreads();
 				const uint32_t roundTag = (round + 1u) << 17;
 				for (uint32_t i = tid; i < w; i += WF_T) {
 					const uint32_t cell = fast ? (uint32_t)(skey[SK((int)i)] & 0x1FFFFFu) : S.gvals[i];
@@ -736,111 +840,127 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				}
 				__syncthreads();
 				WF_STAMP(WP_OFFER);
-				for (uint32_t i = tid; i < w; i += WF_T) {
-					uint32_t cell, cbits;
-					if (fast) {
-						const uint64_t k = skey[SK((int)i)];
-						cell = (uint32_t)(k & 0x1FFFFFu);
-						cbits = lBits + (uint32_t)(k >> 41);
-					} else {
-						cell = S.gvals[i];
-						cbits = (uint32_t)(S.gkeys[i] >> 32);
-					}
-					const float ci = __uint_as_float(cbits);
-					const int pr = (int)(cell / (uint32_t)pc), pcc = (int)(cell - (uint32_t)pr * (uint32_t)pc);
-					const uint8_t* rowBase = state + (int64_t)pr * pc;
-					const Row3 up = load_state3(rowBase - pc, pcc - 1), mid = load_state3(rowBase, pcc - 1), dn = load_state3(rowBase + pc, pcc - 1);
-					const uint32_t mk = candidate_mask(up, mid, dn);
-#pragma unroll
-					for (int j = 0; j < 8; j++) {
-						if (!(mk & (1u << j)))
-							continue;
-						// n = neighbour j.  Is another window cell the first to reach n?
-						const uint32_t ncell = cell + (uint32_t)nbOff[j];
-						const int nr = pr + kDr[j], nc = pcc + kDc[j];
-						const uint32_t mine = i * 8u + (uint32_t)j;
-						const Row3 tu = load_row3(S.tag + ncell - pc - 1), tm = load_row3(S.tag + ncell - 1), td = load_row3(S.tag + ncell + pc - 1);
-						const uint8_t* nrow = state + (int64_t)nr * pc;
-						const Row3 gu = load_state3(nrow - pc, nc - 1), gm = load_state3(nrow, nc - 1), gd = load_state3(nrow + pc, nc - 1);
-						// p'' = n - d_jj reaches n through direction jj: p'' sits at offset -d_jj from n
-						const uint32_t tg[8] = { tm.c, td.c, tu.c, tm.a, td.a, tu.a, td.b, tu.b };
-						const bool oL = gm.a == ST_OCC, oR = gm.c == ST_OCC, oU = gu.b == ST_OCC, oD = gd.b == ST_OCC; // n's orthogonal neighbours
-						bool win = true;
-#pragma unroll
-						for (int jj = 0; jj < 8; jj++) {
-							if (jj == j || (tg[jj] & 0xFFFE0000u) != roundTag)
-								continue; // itself, or not popped in this round
-							// corner rule for p'' -> n: (n.row, p''.col) = (nr, nc - dc) and (p''.row, n.col) = (nr - dr, nc)
-							bool allowed = true;
-							if (kDr[jj] != 0 && kDc[jj] != 0) {
-								const bool oc = kDc[jj] > 0 ? oL : oR;
-								const bool orr = kDr[jj] > 0 ? oU : oD;
-								allowed = !(oc && orr);
-							}
-							const uint32_t other = (tg[jj] & 0x1FFFFu) * 8u + (uint32_t)jj;
-							if (allowed && other < mine)
-								win = false;
+				uint32_t runBase = b;
+				for (uint32_t i0 = 0; i0 < w; i0 += WF_T) {
+					const uint32_t i = i0 + tid;
+					uint32_t cell = 0, cbits = 0, winMask = 0;
+					int pr = 0, pcc = 0;
+					if (i < w) {
+						if (fast) {
+							const uint64_t k = skey[SK((int)i)];
+							cell = (uint32_t)(k & 0x1FFFFFu);
+							cbits = lBits + (uint32_t)(k >> 41);
+						} else {
+							cell = S.gvals[i];
+							cbits = (uint32_t)(S.gkeys[i] >> 32);
 						}
-						if (!win)
-							continue;
-						const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
-						const float pathCost = transitionCost + ci; // heuristics.cpp:135
-						const uint32_t pb = __float_as_uint(pathCost);
-						state[ncell] = (uint8_t)ST_SEEN;
-						cost[(int64_t)(nr - 1) * cols + (nc - 1)] = pathCost;
-						newMin = min(newMin, pb);
-						newOrd = min(newOrd, roundBase + mine);
-						const uint32_t slot = b + atomicAdd(&s_new, 1u);
-						push_entry(slot, ncell, pb, roundBase + mine);
+						pr = (int)(cell / (uint32_t)pc);
+						pcc = (int)(cell - (uint32_t)pr * (uint32_t)pc);
+						const uint8_t* rowBase = state + (int64_t)pr * pc;
+						const Row3 up = load_state3(rowBase - pc, pcc - 1), mid = load_state3(rowBase, pcc - 1), dn = load_state3(rowBase + pc, pcc - 1);
+						const uint32_t mk = candidate_mask(up, mid, dn);
+#pragma unroll
+						for (int j = 0; j < 8; j++) {
+							if (!(mk & (1u << j)))
+								continue;
+							// n = neighbour j.  Is another window cell the first to reach n?
+							const uint32_t ncell = cell + (uint32_t)nbOff[j];
+							const int nr = pr + kDr[j], nc = pcc + kDc[j];
+							const uint32_t mine = i * 8u + (uint32_t)j;
+							const Row3 tu = load_row3(S.tag + ncell - pc - 1), tm = load_row3(S.tag + ncell - 1), td = load_row3(S.tag + ncell + pc - 1);
+							const uint8_t* nrow = state + (int64_t)nr * pc;
+							const Row3 gu = load_state3(nrow - pc, nc - 1), gm = load_state3(nrow, nc - 1), gd = load_state3(nrow + pc, nc - 1);
+							// p'' = n - d_jj reaches n through direction jj: p'' sits at offset -d_jj from n
+							const uint32_t tg[8] = { tm.c, td.c, tu.c, tm.a, td.a, tu.a, td.b, tu.b };
+							const bool oL = gm.a == ST_OCC, oR = gm.c == ST_OCC, oU = gu.b == ST_OCC, oD = gd.b == ST_OCC; // n's orthogonal neighbours
+							bool win = true;
+#pragma unroll
+							for (int jj = 0; jj < 8; jj++) {
+								if (jj == j || (tg[jj] & 0xFFFE0000u) != roundTag)
+									continue; // itself, or not popped in this round
+								// corner rule for p'' -> n: (n.row, p''.col) = (nr, nc - dc) and (p''.row, n.col) = (nr - dr, nc)
+								bool allowed = true;
+								if (kDr[jj] != 0 && kDc[jj] != 0) {
+									const bool oc = kDc[jj] > 0 ? oL : oR;
+									const bool orr = kDr[jj] > 0 ? oU : oD;
+									allowed = !(oc && orr);
+								}
+								const uint32_t other = (tg[jj] & 0x1FFFFu) * 8u + (uint32_t)jj;
+								if (allowed && other < mine)
+									win = false;
+							}
+							if (win)
+								winMask |= 1u << j;
+						}
 					}
+					// ordered slots for this chunk of 512 window cells (ascending i, then j)
+					const uint32_t cw = (uint32_t)__popc(winMask);
+					const uint32_t inclW = wave_incl_add(cw);
+					if (lane == 63)
+						s_wsum[wave] = inclW;
+					__syncthreads(); // also: every state/tag read of this chunk precedes the state stores below
+					uint32_t slot = runBase + inclW - cw, chunkTotal = 0;
+#pragma unroll
+					for (int v = 0; v < WF_W; v++) {
+						const uint32_t t = s_wsum[v];
+						chunkTotal += t;
+						slot += v < wave ? t : 0u;
+					}
+					if (winMask) {
+						const float ci = __uint_as_float(cbits);
+#pragma unroll
+						for (int j = 0; j < 8; j++) {
+							if (!(winMask & (1u << j)))
+								continue;
+							const uint32_t ncell = cell + (uint32_t)nbOff[j];
+							const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
+							const float pathCost = transitionCost + ci; // heuristics.cpp:135
+							const uint32_t pb = __float_as_uint(pathCost);
+							state[ncell] = (uint8_t)ST_SEEN;
+							cost[(int64_t)(pr - 1 + kDr[j]) * cols + (pcc - 1 + kDc[j])] = pathCost;
+							newMin = min(newMin, pb);
+							push_entry(slot++, ncell, pb);
+						}
+					}
+					runBase += chunkTotal;
+					__syncthreads(); // s_wsum is rewritten by the next chunk; its candidate masks must see these state stores
 				}
+				newCount = runBase - b;
 			}
-			if (newMin != 0xFFFFFFFFu) {
-				atomicMin(&s_minNext, newMin);
-				atomicMin(&s_ordMinNext, newOrd);
-			}
-			__syncthreads();
+			newMin = wave_min(newMin);
+			if (lane == 0 && newMin != 0xFFFFFFFFu)
+				atomicMin(&s_minNext[par], newMin);
 			if (kProfile && !hashed) {
 				ph[WP_FBROUNDS]++;
 				ph[WP_FBCYC] += clock64() - tl;
 			}
+			const uint32_t nn = b + newCount;
+			// where the list lives next round
+			bool nextLds = inLds && pushLds;
+			if (!nextLds)
+				__syncthreads(); // HBM list: stores of this round are read back by the next partition
+			else
+				lds_barrier();
 			WF_STAMP(WP_PUSH);
-			const uint32_t nn = b + s_new;
-			const uint32_t nextMin = s_minNext, nextOrd = s_ordMinNext;
-			__syncthreads();
+			lBits = s_minNext[par];
 			if (tid == 0) {
-				s_min = nextMin;
-				s_minNext = 0xFFFFFFFFu;
-				s_ordMin = nextOrd;
-				s_ordMinNext = 0xFFFFFFFFu;
-				s_w = 0;
-				s_b = 0;
-				s_new = 0;
+				s_minNext[par ^ 1] = 0xFFFFFFFFu; // accumulates during the next round; nobody reads it before that round ends
 				s_packFail = 0;
-				s_cand = 0;
-				s_distinct = 0;
 			}
-			__syncthreads();
 			if (nn > S.fcap) {
 				overflow = true;
 				break;
 			}
-			// where the list lives next round
-			if (inLds && !pushLds) {
-				inLds = false; // it was moved to S.f*[nxt] above
+			if (!nextLds) {
 				cur = nxt;
-			} else if (!inLds) {
-				cur = nxt;
-				if (nn <= (uint32_t)WF_LIST / 4) { // small again: bring it back into LDS
-					for (uint32_t i = tid; i < nn; i += WF_T) {
-						lco[i] = ((uint64_t)S.fcost[cur][i] << 32) | S.ford[cur][i];
-						lcell[i] = S.fcell[cur][i];
-					}
-					__syncthreads();
-					inLds = true;
+				if (packable && nn <= (uint32_t)WF_LIST / 2) { // small again: bring it back into LDS
+					for (uint32_t i = tid; i < nn; i += WF_T)
+						lent[i] = S.fent[cur][i];
+					lds_barrier();
+					nextLds = true;
 				}
 			}
-			roundBase += w * 8u;
+			inLds = nextLds;
 			round++;
 			n = nn;
 			WF_STAMP(WP_TAIL);
@@ -873,8 +993,8 @@ int64_t wavefront_workspace_bytes(int rows, int cols)
 {
 	uint32_t fcap, gcap;
 	wf_caps(rows, cols, fcap, gcap);
-	const int64_t gbytes = (padded_cells(rows, cols) * 4 + 255) / 256 * 256;
-	int64_t b = 2 * gbytes + 6ll * fcap * 4 + (int64_t)gcap * 12 + 16;
+	const int64_t pcells = padded_cells(rows, cols);
+	int64_t b = round256(pcells + 16) + round256(pcells * 4 + 16) + 2ll * fcap * 8 + (int64_t)gcap * 12 + 16;
 	return (b + 255) / 256 * 256;
 }
 
