@@ -14,6 +14,17 @@ namespace ppd {
 #define PPD_INLINE __device__ __forceinline__
 
 constexpr double kPi = 3.14159265358979323846;
+
+// ---- obstacle-heuristic fields between the wavefront and the search kernel are stored in 8 x 8 tiles (one tile =
+// 256 contiguous bytes): the wavefront writes each cell once, in ring order, and a ring crosses a tile in a few
+// consecutive rounds, so the four lines of a tile fill up while they are still in L2 instead of one write-back
+// per 4-byte store (row-major: a vertical or diagonal front touches a different line for every cell).
+__host__ __device__ inline size_t field_tiled_index(int cols, int row, int col)
+{
+	const int tpr = (cols + 7) >> 3;
+	return ((size_t)((row >> 3) * tpr + (col >> 3)) << 6) | (size_t)(((row & 7) << 3) | (col & 7));
+}
+__host__ __device__ inline size_t field_tiled_elems(int rows, int cols) { return (size_t)((rows + 7) >> 3) * (size_t)((cols + 7) >> 3) * 64; }
 constexpr double kPi2 = 1.57079632679489661923;
 
 struct Pose {

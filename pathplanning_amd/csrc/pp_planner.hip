@@ -72,6 +72,7 @@ struct SearchArgs {
 	float rsRev, rsFwd, rsSw; // Reeds-Shepp cost weights as floats (reeds_shepp.cpp:654)
 	int maxNodes;
 	size_t cells;
+	int64_t fieldElems; // floats per query in costFields (8 x 8-tiled obstacle-heuristic field)
 };
 
 struct DevResult {
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	uint32_t* keymap = keymapBase + (size_t)q * A.ks.size();
 	uint32_t* expanded = expandedBase + (size_t)q * maxNodes;
 	RsLogEntry* rsLog = rsLogBase + (size_t)q * kRsLogCap;
-	const float* field = costFields + (size_t)q * A.cells;
+	const float* field = costFields + (size_t)q * A.fieldElems;
 
 	// goal / start poses go through the Pose2d constructor on the caller's side (theta wrapped)
 	const Pose start = { starts[3 * q], starts[3 * q + 1], wrap_theta(starts[3 * q + 2]) };
@@ -874,6 +875,7 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 	A.rsSw = (float)params->direction_switching_cost;
 	A.maxNodes = max_nodes_per_query;
 	A.cells = map->cells();
+	A.fieldElems = (int64_t)field_tiled_elems(map->desc.rows, map->desc.cols);
 	// key space: every discrete pose a state inside the bounds (plus one arc of slack) can take
 	{
 		const double sres = params->spatial_resolution, ares = params->angular_resolution;
@@ -906,7 +908,7 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 			e = hipMalloc(ptr, bytes ? bytes : 1);
 	};
 	alloc((void**)&p->table, tableBytes);
-	alloc((void**)&p->costFields, B * A.cells * sizeof(float));
+	alloc((void**)&p->costFields, B * (size_t)A.fieldElems * sizeof(float));
 	alloc((void**)&p->wfWorkspace, (size_t)p->wfBytesPerSlot * p->wfSlots);
 	alloc((void**)&p->wfError, 8);
 	alloc((void**)&p->goalCells, B * 4);
@@ -1002,7 +1004,7 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	PP_HIP_TRY(hipGetLastError());
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
 	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, planner->goalCells, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
-		planner->wfError));
+		planner->wfError, nullptr, /*tiledOut=*/true));
 	PP_HIP_TRY(hipEventRecord(planner->e1, s));
 	if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,

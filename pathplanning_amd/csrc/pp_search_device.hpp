@@ -89,7 +89,7 @@ PPD_INLINE double obstacle_heuristic(const HeurView& h, const MapView& m, const 
 	world_to_cell(m, state.x, state.y, row, col);
 	if (!inside_map(m, row, col))
 		return euclidean;
-	const float c = field[(size_t)row * m.cols + col];
+	const float c = field[field_tiled_index(m.cols, row, col)]; // tiled layout, see pp_device.hpp
 	if (c == __builtin_huge_valf())
 		return euclidean;
 	const double heuristic = (double)(c * h.obstCostMult - h.obstDiagRes);

@@ -39,24 +39,34 @@ constexpr uint32_t kInfBits = 0x7F800000u;
 constexpr uint32_t kOccBits = 0x7FC00000u; // NaN pattern marking occupied / border cells in the working grid
 
 struct WfSlot {
-	uint8_t* state;      // [(rows+2) * pc] one byte per padded cell: free / occupied (and border) / discovered
-	uint32_t* tag;       // [(rows+2) * pc] (round+1) << 17 | rank, fallback claim resolution
+	uint8_t* state;      // 8 x 8-tiled padded grid, one byte per cell: free / occupied (and border) / discovered
+	uint32_t* tag;       // [(rows+2) * (cols+2)] row-major: (round+1) << 17 | rank, fallback claim resolution
 	uint64_t* fent[2];   // open list in HBM (ping-pong), [fcap]: cost bits << 32 | padded cell, in push order
 	uint64_t* gkeys;     // fallback sort buffers in HBM, [gcap] (gcap = pow2 >= fcap)
 	uint32_t* gvals;
 	uint32_t fcap, gcap;
 };
 
-__host__ __device__ inline int padded_stride(int cols) { return (cols + 2 + 7) & ~7; }
-__host__ __device__ inline int64_t padded_cells(int rows, int cols) { return (int64_t)(rows + 2) * padded_stride(cols); }
+// The state grid is padded by one border cell on every side and stored in 8 x 8 tiles of 64 bytes (one cache
+// line): a ring of the wavefront crosses a tile during ~8 consecutive rounds, so the lines the 3 x 3 neighbourhood
+// reads of a goal touch stay few (a row-major grid has a vertical front touch three new lines per cell, and with
+// 64 goals sharing a 4 MiB L2 every such read went to HBM: 181 B fetched per cell, measured).
+__host__ __device__ inline int state_tiles_per_row(int cols) { return (cols + 2 + 7) >> 3; }
+__host__ __device__ inline int64_t state_bytes(int rows, int cols) { return (int64_t)((rows + 2 + 7) >> 3) * state_tiles_per_row(cols) * 64; }
+__host__ __device__ inline int64_t padded_cells(int rows, int cols) { return (int64_t)(rows + 2) * (cols + 2); }
 __host__ __device__ inline int64_t round256(int64_t b) { return (b + 255) / 256 * 256; }
+/// byte address of padded cell (pr, pcc) in the tiled state grid
+__device__ __forceinline__ uint32_t st_addr(int tpr, int pr, int pcc) { return ((uint32_t)((pr >> 3) * tpr + (pcc >> 3)) << 6) | (uint32_t)(((pr & 7) << 3) | (pcc & 7)); }
+// cells travel as (padded row << 16 | padded col); the packed window key holds them in 22 bits (11 + 11)
+__device__ __forceinline__ uint32_t pack22(uint32_t cell) { return ((cell >> 16) << 11) | (cell & 0x7FFu); }
+__device__ __forceinline__ uint32_t unpack22(uint32_t k) { return ((k >> 11) << 16) | (k & 0x7FFu); }
 
-__device__ __forceinline__ WfSlot slot_view(void* base, int64_t bytesPerSlot, int slot, int64_t pcells, uint32_t fcap, uint32_t gcap)
+__device__ __forceinline__ WfSlot slot_view(void* base, int64_t bytesPerSlot, int slot, int64_t stBytes, int64_t pcells, uint32_t fcap, uint32_t gcap)
 {
 	char* p = (char*)base + (int64_t)slot * bytesPerSlot;
 	WfSlot s;
 	s.state = (uint8_t*)p;
-	p += round256(pcells + 16); // row loads may run a few bytes past the last row
+	p += round256(stBytes);
 	s.tag = (uint32_t*)p;
 	p += round256(pcells * 4 + 16);
 	for (int k = 0; k < 2; k++) {
@@ -250,25 +260,43 @@ __device__ __forceinline__ void bitonic_sort_packed(uint64_t* keys, int P)
 constexpr int kDr[8] = { 0, -1, 1, 0, -1, 1, -1, 1 };
 constexpr int kDc[8] = { -1, -1, -1, 1, 1, 1, 0, 0 };
 
-/// three consecutive state bytes (c-1, c, c+1) of one padded row, fetched as ONE aligned 8-byte word:
-/// base4 = (c-1) & ~3 always covers c-1 .. c+1 (offset <= 3, so offset + 2 <= 5 < 8)
+/// kDr[j] / kDc[j] for a run-time j without a memory table: 2-bit fields (value + 1)
+__device__ __forceinline__ int dir_dr(int j) { return (int)((0x8861u >> (2 * j)) & 3u) - 1; } // {0,-1,1,0,-1,1,-1,1} + 1 = {1,0,2,1,0,2,0,2}
+__device__ __forceinline__ int dir_dc(int j) { return (int)((0x5A80u >> (2 * j)) & 3u) - 1; } // {-1,-1,-1,1,1,1,0,0} + 1 = {0,0,0,2,2,2,1,1}
+
 struct Row3 {
 	uint32_t a, b, c;
 };
-__device__ __forceinline__ Row3 load_state3(const uint8_t* rowBase, int cm1)
+/// States of the 3 x 3 block around padded cell (pr, pcc) from the tiled grid.  A tile row is 8 aligned bytes, so each
+/// of the three rows is ONE 8-byte load; only cells in the first / last column of a tile (1 in 4) also need the
+/// adjacent tile's edge byte.
+__device__ __forceinline__ void load_state_nbhd(const uint8_t* __restrict__ state, int tpr, int pr, int pcc, Row3& up, Row3& mid, Row3& dn)
 {
-	const int base4 = cm1 & ~3;
-	struct __attribute__((aligned(4))) U2 {
-		uint32_t x, y;
-	};
-	const U2 v = *reinterpret_cast<const U2*>(rowBase + base4); // 4-byte aligned: row stride is a multiple of 8 bytes
-	const unsigned long long w = ((unsigned long long)v.y << 32) | v.x;
-	const int sh = (cm1 - base4) * 8;
-	Row3 r;
-	r.a = (uint32_t)(w >> sh) & 0xFFu;
-	r.b = (uint32_t)(w >> (sh + 8)) & 0xFFu;
-	r.c = (uint32_t)(w >> (sh + 16)) & 0xFFu;
-	return r;
+	const int x = pcc & 7;
+	uint32_t base[3];
+	unsigned long long w[3];
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		const int rr = pr - 1 + k;
+		base[k] = ((uint32_t)((rr >> 3) * tpr + (pcc >> 3)) << 6) | (uint32_t)((rr & 7) << 3);
+		w[k] = *reinterpret_cast<const unsigned long long*>(state + base[k]);
+	}
+	uint32_t side[3] = { 0, 0, 0 };
+	if (x == 0 || x == 7) {
+		const int off = x ? 64 : -57; // same row of the next tile (its byte 0) / of the previous tile (its byte 7)
+#pragma unroll
+		for (int k = 0; k < 3; k++)
+			side[k] = state[(int)base[k] + off];
+	}
+	Row3* out[3] = { &up, &mid, &dn };
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		const uint32_t lo = (uint32_t)(w[k] >> ((x ? x - 1 : 0) * 8)) & 0xFFu;
+		const uint32_t hi = (uint32_t)(w[k] >> ((x < 7 ? x + 1 : 7) * 8)) & 0xFFu;
+		out[k]->a = x == 0 ? side[k] : lo;
+		out[k]->b = (uint32_t)(w[k] >> (x * 8)) & 0xFFu;
+		out[k]->c = x == 7 ? side[k] : hi;
+	}
 }
 /// three consecutive 32-bit words (fallback path: rank words)
 __device__ __forceinline__ Row3 load_row3(const uint32_t* p)
@@ -309,7 +337,7 @@ __device__ __forceinline__ uint32_t candidate_mask(const Row3& up, const Row3& m
 }
 
 // kProfile: diagnostic build -- per goal {init, min, partition, sort, offer, push, tail} shader-clock sums + rounds, sum(w), sum(P)
-enum { WP_INIT = 0, WP_MIN, WP_PART, WP_SORT, WP_OFFER, WP_PUSH, WP_TAIL, WP_ROUNDS, WP_SUMW, WP_SUMP, WP_FBROUNDS, WP_FBCYC, WP_COUNT };
+enum { WP_INIT = 0, WP_MIN, WP_PART, WP_SORT, WP_OFFER, WP_PUSH, WP_TAIL, WP_ROUNDS, WP_SUMW, WP_SUMP, WP_FBROUNDS, WP_FBCYC, WP_O_WAIT, WP_O_LOAD, WP_O_COUNT, WP_O_INSERT, WP_COUNT };
 
 constexpr int WF_LIST = 4096; // open-list entries kept in LDS (32 KiB); beyond that the list lives in HBM
 constexpr int WF_NB = 2048;   // buckets of the rank sort
@@ -434,7 +462,8 @@ __device__ __forceinline__ void rank_sort(uint64_t* skey, uint32_t* hist, uint32
 #endif
 template <bool kProfile>
 __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapView m, int nGoals, const int32_t* __restrict__ goalCells, float* __restrict__ costOut,
-	void* workspace, int64_t bytesPerSlot, uint32_t fcap, uint32_t gcap, int32_t* errorFlag, unsigned long long* __restrict__ prof, int* __restrict__ goalCounter)
+	void* workspace, int64_t bytesPerSlot, uint32_t fcap, uint32_t gcap, int32_t* errorFlag, unsigned long long* __restrict__ prof, int* __restrict__ goalCounter,
+	int tiledOut)
 {
 	unsigned long long ph[WP_COUNT];
 	unsigned long long tl = 0;
@@ -459,14 +488,20 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const unsigned long long ltMask = (1ull << lane) - 1ull;
 	const int cols = m.cols, rows = m.rows;
-	const int pc = padded_stride(cols); // padded row stride of the state grid (bytes), multiple of 8
+	const int pc = cols + 2;             // row stride of the (row-major) tag grid
+	const int tpr = state_tiles_per_row(cols);
 	const int64_t cells = (int64_t)rows * cols;
-	const int64_t pcells = (int64_t)(rows + 2) * pc;
-	const bool packable = pcells <= (1 << 21); // cell index fits the packed window key
-	WfSlot S = slot_view(workspace, bytesPerSlot, blockIdx.x, pcells, fcap, gcap);
+	const int64_t pcells = padded_cells(rows, cols);
+	const int64_t stBytes = state_bytes(rows, cols);
+	const int64_t fieldElems = tiledOut ? (int64_t)field_tiled_elems(rows, cols) : cells; // floats per goal in costOut
+	const bool packable = rows + 2 <= 2047 && cols + 2 <= 2047; // (row, col) fits the 22 cell bits of the packed window key
+	WfSlot S = slot_view(workspace, bytesPerSlot, blockIdx.x, stBytes, pcells, fcap, gcap);
 	uint8_t* const state = S.state;
 	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
-	const int nbOff[8] = { -1, -pc - 1, pc - 1, 1, -pc + 1, pc + 1, -pc, pc }; // padded-index offsets of kDr/kDc
+	const int nbOff[8] = { -1, -65536 - 1, 65536 - 1, 1, -65536 + 1, 65536 + 1, -65536, 65536 }; // (row << 16 | col) offsets of kDr/kDc
+	// index of map cell (r, c) in this goal's output field
+	auto out_index = [&](int r, int c) -> size_t { return tiledOut ? field_tiled_index(cols, r, c) : (size_t)r * cols + c; };
+	auto tag_index = [&](uint32_t cell) -> uint32_t { return (cell >> 16) * (uint32_t)pc + (cell & 0xFFFFu); };
 
 	for (int i = tid; i < WF_NB; i += WF_T)
 		hist[i] = 0u;
@@ -485,19 +520,31 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				ph[i] = 0;
 			tl = clock64();
 		}
-		float* cost = costOut + (int64_t)g * cells;
-		uint32_t* costBits = reinterpret_cast<uint32_t*>(cost);
+		float* cost = costOut + (int64_t)g * fieldElems;
 		// ---- every cell starts at +inf / unexplored (heuristics.cpp:108-113); state: occupied cells and the border
-		for (int64_t i = tid; i < cells; i += WF_T)
-			costBits[i] = kInfBits;
-		for (int pr = 0; pr < rows + 2; pr++) {
-			const bool brow = pr == 0 || pr == rows + 1;
-			for (int pcc = tid; pcc < pc; pcc += WF_T) {
-				uint8_t v = (uint8_t)ST_OCC;
-				if (!brow && pcc >= 1 && pcc <= cols)
-					v = m.occ8[(int64_t)(pr - 1) * cols + (pcc - 1)] ? (uint8_t)ST_OCC : (uint8_t)ST_FREE;
-				state[(int64_t)pr * pc + pcc] = v;
+		{
+			uint4* c4 = reinterpret_cast<uint4*>(cost); // fieldElems * 4 bytes is a multiple of 16 when tiled; row-major: tail below
+			const int64_t n4 = fieldElems >> 2;
+			for (int64_t i = tid; i < n4; i += WF_T)
+				c4[i] = make_uint4(kInfBits, kInfBits, kInfBits, kInfBits);
+			for (int64_t i = (n4 << 2) + tid; i < fieldElems; i += WF_T)
+				reinterpret_cast<uint32_t*>(cost)[i] = kInfBits;
+		}
+		// one tile row (8 bytes) per thread and step; everything outside the map is "occupied"
+		for (int64_t t = tid; t < (stBytes >> 3); t += WF_T) {
+			const int tile = (int)(t >> 3), trow = (int)(t & 7);
+			const int tr = tile / tpr, tc = tile - tr * tpr;
+			const int pr = (tr << 3) + trow, r = pr - 1;
+			unsigned long long v = 0;
+#pragma unroll
+			for (int x = 0; x < 8; x++) {
+				const int c = (tc << 3) + x - 1;
+				uint32_t st = ST_OCC;
+				if (r >= 0 && r < rows && c >= 0 && c < cols)
+					st = m.occ8[(int64_t)r * cols + c] ? ST_OCC : ST_FREE;
+				v |= (unsigned long long)st << (8 * x);
 			}
+			reinterpret_cast<unsigned long long*>(state)[t] = v;
 		}
 		const int32_t start = goalCells[g];
 		if (tid == 0) {
@@ -514,9 +561,9 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		int cur = 0;           // ping-pong index of the HBM list
 		if (tid == 0) {
 			const int sr = start / cols, sc = start - sr * cols;
-			const uint32_t sp = (uint32_t)((sr + 1) * pc + (sc + 1));
-			state[sp] = (uint8_t)ST_SEEN; // the reference pushes the goal cell even when it is occupied
-			cost[start] = 0.0f;
+			const uint32_t sp = ((uint32_t)(sr + 1) << 16) | (uint32_t)(sc + 1);
+			state[st_addr(tpr, sr + 1, sc + 1)] = (uint8_t)ST_SEEN; // the reference pushes the goal cell even when it is occupied
+			cost[out_index(sr, sc)] = 0.0f;
 			if (inLds)
 				lent[0] = (uint64_t)sp; // cost 0
 			else
@@ -538,7 +585,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			WF_STAMP(WP_MIN);
 			// ---- partition: window (cost < fl(L+1)) -> sort buffer; the rest stays in the open list IN ORDER.
 			// The list is kept in push order, so "pushed later" == "further back": a window entry is packed as
-			// (cost - L : 23 | ~position : 20 | cell : 21) and sorting those keys yields the reference's pop order
+			// (cost - L : 23 | ~position : 19 | row, col : 22) and sorting those keys yields the reference's pop order
 			// (cost ascending, most recent push first).  Slots come from ballots + one 64-entry scan per chunk.
 			bool fast = true;
 			uint32_t w = 0, b = 0;
@@ -571,7 +618,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					const bool inW = i < n && c < hiBits;
 					if (inW) {
 						const uint32_t wslot = (off >> 16) + (uint32_t)__popcll(bw[u] & ltMask);
-						skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0xFFFFFu - i) << 21) | (uint64_t)cell;
+						skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0x7FFFFu - i) << 22) | (uint64_t)pack22(cell);
 					} else if (i < n) {
 						const uint32_t rslot = (off & 0xFFFFu) + (uint32_t)__popcll(br[u] & ltMask);
 						lent[rslot] = e[u];
@@ -609,10 +656,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 							if (inW) {
 								const uint32_t wslot = wRun + (off >> 16) + (uint32_t)__popcll(bw[u] & ltMask);
 								if (fast) {
-									if (!packable || i >= (1u << 20) || (c - lBits) >= (1u << 23))
+									if (!packable || i >= (1u << 19) || (c - lBits) >= (1u << 23))
 										s_packFail = 1;
 									if (wslot < (uint32_t)WF_LCAP)
-										skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0xFFFFFu - (i & 0xFFFFFu)) << 21) | (uint64_t)(cell & 0x1FFFFFu);
+										skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0x7FFFFu - (i & 0x7FFFFu)) << 22) | (uint64_t)(pack22(cell) & 0x3FFFFFu);
 								} else if (wslot < S.gcap) {
 									S.gkeys[wslot] = ((uint64_t)c << 32) | (uint64_t)(0xFFFFFFFFu - i);
 									S.gvals[wslot] = cell;
@@ -680,7 +727,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				for (uint32_t i = tid; i < b; i += WF_T)
 					S.fent[nxt][i] = lent[i];
 			};
-			uint32_t myCell[4] = { 0, 0, 0, 0 }, myCost[4] = { 0, 0, 0, 0 }, myMask[4] = { 0, 0, 0, 0 }, myOut[4] = { 0, 0, 0, 0 };
+			uint32_t myCell[4] = { 0, 0, 0, 0 }, myCost[4] = { 0, 0, 0, 0 }, myMask[4] = { 0, 0, 0, 0 };
 			bool hashed = false;
 			if (fast && w <= 4u * WF_T) {
 #pragma unroll
@@ -688,23 +735,22 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					const uint32_t i = tid + q * WF_T;
 					if (i < w) {
 						const uint64_t k = skey[SK((int)i)];
-						myCell[q] = (uint32_t)(k & 0x1FFFFFu);
+						myCell[q] = unpack22((uint32_t)k & 0x3FFFFFu);
 						myCost[q] = lBits + (uint32_t)(k >> 41);
 					}
 				}
 				__syncthreads(); // the state bytes stored by the previous round are visible from here on
+				unsigned long long ts_ = 0;
+				if (kProfile) {
+					ts_ = clock64();
+					ph[WP_O_WAIT] += ts_ - tl;
+				}
 				Row3 up[4], mid[4], dn[4];
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					const uint32_t i = tid + q * WF_T;
-					if (i < w) {
-						const int pr = (int)(myCell[q] / (uint32_t)pc), pcc = (int)(myCell[q] - (uint32_t)pr * (uint32_t)pc);
-						const uint8_t* rowBase = state + (int64_t)pr * pc;
-						myOut[q] = (uint32_t)((pr - 1) * cols + (pcc - 1)); // index of the cell in the (unpadded) output field
-						up[q] = load_state3(rowBase - pc, pcc - 1);
-						mid[q] = load_state3(rowBase, pcc - 1);
-						dn[q] = load_state3(rowBase + pc, pcc - 1);
-					}
+					if (i < w)
+						load_state_nbhd(state, tpr, (int)(myCell[q] >> 16), (int)(myCell[q] & 0xFFFFu), up[q], mid[q], dn[q]);
 				}
 				uint32_t cnt = 0;
 #pragma unroll
@@ -715,10 +761,17 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						cnt += __popc(myMask[q]);
 					}
 				}
+				if (kProfile) {
+					const unsigned long long now_ = clock64();
+					ph[WP_O_LOAD] += now_ - ts_;
+					ts_ = now_;
+				}
 				cnt = wave_incl_add(cnt);
 				if (lane == 63 && cnt)
 					atomicAdd(&s_cand, cnt);
 				lds_barrier();
+				if (kProfile)
+					ph[WP_O_COUNT] += clock64() - ts_;
 				// The claim table has WF_HCAP slots; the round may use it only when every candidate (counted with
 				// duplicates, so an upper bound on distinct cells) fits with room to spare: insertion then always ends.
 				hashed = s_cand <= (uint32_t)(WF_HCAP * 3 / 4);
@@ -732,49 +785,45 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					reinterpret_cast<uint4*>(hkey)[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
 				}
 				lds_barrier();
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					const uint32_t i = tid + q * WF_T;
-					const uint32_t mk = myMask[q];
-					if (i < w && mk) {
-#pragma unroll
-						for (int j = 0; j < 8; j++) {
-							if (!(mk & (1u << j)))
-								continue;
-							const uint32_t ncell = myCell[q] + (uint32_t)nbOff[j];
-							const uint32_t key = i * 8u + (uint32_t)j;
-							uint32_t h = (ncell * 2654435761u) >> (32 - 12); // WF_HCAP = 4096 = 2^12
-							for (;;) {
-								const uint32_t old = atomicCAS(&hcell[h], 0u, ncell + 1u);
-								if (old == 0u || old == ncell + 1u) {
-									atomicMin(&hkey[h], key);
-									break;
-								}
-								h = (h + 1) & (WF_HCAP - 1);
-							}
+				// candidates of this lane as one bit set (bit q*8+j); lanes walk their own set bits, so the wave iterates
+				// max-popcount times (about a dozen) instead of over all 32 (q, j) combinations
+				const uint32_t candBits = myMask[0] | (myMask[1] << 8) | (myMask[2] << 16) | (myMask[3] << 24);
+				for (uint32_t rem = candBits; rem;) {
+					const int bit = __ffs((int)rem) - 1;
+					rem &= rem - 1u;
+					const int q = bit >> 3, j = bit & 7;
+					const uint32_t pcell = q == 0 ? myCell[0] : q == 1 ? myCell[1] : q == 2 ? myCell[2] : myCell[3];
+					const uint32_t ncell = pcell + (uint32_t)(dir_dr(j) * 65536 + dir_dc(j));
+					const uint32_t key = ((uint32_t)tid + (uint32_t)q * WF_T) * 8u + (uint32_t)j;
+					uint32_t h = (ncell * 2654435761u) >> (32 - 12); // WF_HCAP = 4096 = 2^12
+					for (;;) {
+						const uint32_t old = atomicCAS(&hcell[h], 0u, ncell + 1u);
+						if (old == 0u || old == ncell + 1u) {
+							atomicMin(&hkey[h], key);
+							break;
 						}
+						h = (h + 1) & (WF_HCAP - 1);
 					}
 				}
 				lds_barrier();
+				if (kProfile)
+					ph[WP_O_INSERT] += clock64() - tl;
 				WF_STAMP(WP_OFFER);
 				// the winners: a lane first finds its wins (bit q*8+j); a block scan then hands out open-list slots in
 				// the reference's push order, i.e. ascending (i, j) = ascending (q, thread, j)
 				uint32_t winBits = 0;
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					const uint32_t i = tid + q * WF_T;
-					const uint32_t mk = (i < w) ? myMask[q] : 0u;
-#pragma unroll
-					for (int j = 0; j < 8; j++) {
-						if (!(mk & (1u << j)))
-							continue;
-						const uint32_t ncell = myCell[q] + (uint32_t)nbOff[j];
-						uint32_t h = (ncell * 2654435761u) >> (32 - 12);
-						while (hcell[h] != ncell + 1u)
-							h = (h + 1) & (WF_HCAP - 1);
-						if (hkey[h] == i * 8u + (uint32_t)j)
-							winBits |= 1u << (q * 8 + j);
-					}
+				for (uint32_t rem = candBits; rem;) {
+					const int bit = __ffs((int)rem) - 1;
+					rem &= rem - 1u;
+					const int q = bit >> 3, j = bit & 7;
+					const uint32_t pcell = q == 0 ? myCell[0] : q == 1 ? myCell[1] : q == 2 ? myCell[2] : myCell[3];
+					const uint32_t ncell = pcell + (uint32_t)(dir_dr(j) * 65536 + dir_dc(j));
+					const uint32_t key = ((uint32_t)tid + (uint32_t)q * WF_T) * 8u + (uint32_t)j;
+					uint32_t h = (ncell * 2654435761u) >> (32 - 12);
+					while (hcell[h] != ncell + 1u)
+						h = (h + 1) & (WF_HCAP - 1);
+					if (hkey[h] == key)
+						winBits |= 1u << bit;
 				}
 				// per-q counts packed in 16-bit fields (a field never exceeds 4096)
 				const uint32_t c01 = (uint32_t)__popc(winBits & 0xFFu) | ((uint32_t)__popc(winBits & 0xFF00u) << 16);
@@ -816,8 +865,9 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
 						const float pathCost = transitionCost + ci; // heuristics.cpp:135
 						const uint32_t pb = __float_as_uint(pathCost);
-						state[ncell] = (uint8_t)ST_SEEN;
-						cost[(int)myOut[q] + kDr[j] * cols + kDc[j]] = pathCost;
+						const int nr = (int)(ncell >> 16), nc = (int)(ncell & 0xFFFFu);
+						state[st_addr(tpr, nr, nc)] = (uint8_t)ST_SEEN;
+						cost[out_index(nr - 1, nc - 1)] = pathCost;
 						newMin = min(newMin, pb);
 						push_entry(slot++, ncell, pb);
 					}
@@ -835,8 +885,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				__syncthreads();
 				const uint32_t roundTag = (round + 1u) << 17;
 				for (uint32_t i = tid; i < w; i += WF_T) {
-					const uint32_t cell = fast ? (uint32_t)(skey[SK((int)i)] & 0x1FFFFFu) : S.gvals[i];
-					S.tag[cell] = roundTag | i;
+					const uint32_t cell = fast ? unpack22((uint32_t)skey[SK((int)i)] & 0x3FFFFFu) : S.gvals[i];
+					S.tag[tag_index(cell)] = roundTag | i;
 				}
 				__syncthreads();
 				WF_STAMP(WP_OFFER);
@@ -848,16 +898,16 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					if (i < w) {
 						if (fast) {
 							const uint64_t k = skey[SK((int)i)];
-							cell = (uint32_t)(k & 0x1FFFFFu);
+							cell = unpack22((uint32_t)k & 0x3FFFFFu);
 							cbits = lBits + (uint32_t)(k >> 41);
 						} else {
 							cell = S.gvals[i];
 							cbits = (uint32_t)(S.gkeys[i] >> 32);
 						}
-						pr = (int)(cell / (uint32_t)pc);
-						pcc = (int)(cell - (uint32_t)pr * (uint32_t)pc);
-						const uint8_t* rowBase = state + (int64_t)pr * pc;
-						const Row3 up = load_state3(rowBase - pc, pcc - 1), mid = load_state3(rowBase, pcc - 1), dn = load_state3(rowBase + pc, pcc - 1);
+						pr = (int)(cell >> 16);
+						pcc = (int)(cell & 0xFFFFu);
+						Row3 up, mid, dn;
+						load_state_nbhd(state, tpr, pr, pcc, up, mid, dn);
 						const uint32_t mk = candidate_mask(up, mid, dn);
 #pragma unroll
 						for (int j = 0; j < 8; j++) {
@@ -867,9 +917,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 							const uint32_t ncell = cell + (uint32_t)nbOff[j];
 							const int nr = pr + kDr[j], nc = pcc + kDc[j];
 							const uint32_t mine = i * 8u + (uint32_t)j;
-							const Row3 tu = load_row3(S.tag + ncell - pc - 1), tm = load_row3(S.tag + ncell - 1), td = load_row3(S.tag + ncell + pc - 1);
-							const uint8_t* nrow = state + (int64_t)nr * pc;
-							const Row3 gu = load_state3(nrow - pc, nc - 1), gm = load_state3(nrow, nc - 1), gd = load_state3(nrow + pc, nc - 1);
+							const uint32_t tn = tag_index(ncell);
+							const Row3 tu = load_row3(S.tag + tn - pc - 1), tm = load_row3(S.tag + tn - 1), td = load_row3(S.tag + tn + pc - 1);
+							Row3 gu, gm, gd;
+							load_state_nbhd(state, tpr, nr, nc, gu, gm, gd);
 							// p'' = n - d_jj reaches n through direction jj: p'' sits at offset -d_jj from n
 							const uint32_t tg[8] = { tm.c, td.c, tu.c, tm.a, td.a, tu.a, td.b, tu.b };
 							const bool oL = gm.a == ST_OCC, oR = gm.c == ST_OCC, oU = gu.b == ST_OCC, oD = gd.b == ST_OCC; // n's orthogonal neighbours
@@ -916,8 +967,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 							const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
 							const float pathCost = transitionCost + ci; // heuristics.cpp:135
 							const uint32_t pb = __float_as_uint(pathCost);
-							state[ncell] = (uint8_t)ST_SEEN;
-							cost[(int64_t)(pr - 1 + kDr[j]) * cols + (pcc - 1 + kDc[j])] = pathCost;
+							state[st_addr(tpr, pr + kDr[j], pcc + kDc[j])] = (uint8_t)ST_SEEN;
+							cost[out_index(pr - 1 + kDr[j], pcc - 1 + kDc[j])] = pathCost;
 							newMin = min(newMin, pb);
 							push_entry(slot++, ncell, pb);
 						}
@@ -994,7 +1045,7 @@ int64_t wavefront_workspace_bytes(int rows, int cols)
 	uint32_t fcap, gcap;
 	wf_caps(rows, cols, fcap, gcap);
 	const int64_t pcells = padded_cells(rows, cols);
-	int64_t b = round256(pcells + 16) + round256(pcells * 4 + 16) + 2ll * fcap * 8 + (int64_t)gcap * 12 + 16;
+	int64_t b = round256(state_bytes(rows, cols)) + round256(pcells * 4 + 16) + 2ll * fcap * 8 + (int64_t)gcap * 12 + 16;
 	return (b + 255) / 256 * 256;
 }
 
@@ -1010,7 +1061,7 @@ int wavefront_resident_blocks()
 }
 
 hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
-	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev)
+	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev, bool tiledOut)
 {
 	if (nGoals <= 0)
 		return hipSuccess;
@@ -1023,10 +1074,10 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 		return e;
 	if (profDev)
 		hipLaunchKernelGGL(k_wavefront<true>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1));
+			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0);
 	else
 		hipLaunchKernelGGL(k_wavefront<false>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1));
+			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0);
 	return hipGetLastError();
 }
 

@@ -19,7 +19,7 @@ ctx = pa.Context(0)
 m = synthetic.make_map(1024, 24, seed=1)
 ms, val = synthetic.upload(ctx, m)
 goals = synthetic.sample_valid_poses(val, m, G, seed=2000)[:, :2].copy()
-cnt = np.zeros((G, 12), dtype=np.uint64)
+cnt = np.zeros((G, 16), dtype=np.uint64)
 for it in range(2):
     ctx.timer_start()
     check(ctx.lib.pp_obstacle_heuristic_profile(ms.h, G, ptr(np.ascontiguousarray(goals)), ptr(cnt)))
@@ -33,6 +33,7 @@ for i, nm in enumerate(names):
     print("  %-9s %5.1f %%  %.0f cycles/round" % (nm, 100 * c[:, i].sum() / tot, c[:, i].sum() / c[:, 7].sum()))
 print("cycles/goal %.3g" % (c[:, :7].sum(1).mean()))
 print("fallback rounds %.1f %%, their push phase %.1f %% of all cycles" % (100 * c[:, 10].sum() / c[:, 7].sum(), 100 * c[:, 11].sum() / tot))
+print("offer: store-wait %.0f  loads %.0f  count+barrier %.0f  (whole offer to end of insert %.0f) cycles/round" % tuple(c[:, k].sum() / c[:, 7].sum() for k in (12, 13, 14, 15)))
 G2 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 if G2:
     goals2 = synthetic.sample_valid_poses(val, m, G2, seed=2001)[:, :2].copy()
