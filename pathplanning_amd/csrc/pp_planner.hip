@@ -181,6 +181,12 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	}
 	int myNode = -1; // node index of the child staged in this lane's slot (-1: none / not pushed)
 	int rsNode = -1; // same for the Reeds-Shepp slot (wave-uniform)
+	// Prefetch of the probable NEXT pop: while a node is expanded, lane k < 24 loads 32-bit word k of the record at the
+	// head of the open list.  If that node is popped next (and is not a staged child) its fields come out of these
+	// registers with v_readlane instead of a dependent HBM round trip.
+	int pfNode = -1;
+	uint32_t pfWord = 0u;
+	bool pfDead = false; // the prefetched node was replaced (ProcessPossibleShortcut) after it was fetched
 	if (lane == 0)
 		Mt64::seed(mt, seeds[q]);
 	FrontLane front;
@@ -315,6 +321,17 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				pSin = c_sin[slot];
 				pCos = c_cos[slot];
 				pKey = c_key[slot];
+			} else if (ni == pfNode) {
+				auto dbl = [&](int wi) { return __hiloint2double((int)lane_read(pfWord, wi + 1), (int)lane_read(pfWord, wi)); };
+				px = dbl(0);
+				py = dbl(2);
+				pt = dbl(4);
+				pPathCost = dbl(6);
+				pH = dbl(12);
+				pSin = dbl(14);
+				pCos = dbl(16);
+				pKey = lane_read(pfWord, 19);
+				pDead = pfDead || ((lane_read(pfWord, 20) >> 16) & 0xFFu) != 0u;
 			} else {
 				const Node nd = nodes[ni];
 				px = nd.x;
@@ -380,6 +397,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				if (packed)
 					st = keymap[key];
 				hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
+				// Voronoi term of the full-length arc: its only map read (the last sample, Q8) is issued with the look-ups
+				const double voroFull = voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
 				float lastValidRatio;
 				int checks = 0;
 				ok = true;
@@ -403,7 +422,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				laneStateChecks += checks;
 				if (ok) {
 					const double pathCost = (a.backward ? A.rp.reverseMult : A.rp.forwardMult) * a.length;
-					const double voro = voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
+					const double voro = pathValid ? voroFull : voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
 					const double cost = pathCost + 0.0 + voro; // switching cost is always 0 (hybrid_a_star.cpp:142)
 					len = a.length;
 					gcost = pPathCost + cost;
@@ -414,6 +433,31 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			}
 			if (ok && key == pKey)
 				st = kExplored; // the parent's cell was marked explored just above (a_star.h:381)
+			// open-list node already in this child's cell: its pose / cost (needed by ProcessPossibleShortcut) is fetched
+			// by the child's own lane now, all lanes at once, instead of one dependent load per child in the loop below
+			double fpx = 0.0, fpy = 0.0, fpt = 0.0, fptot = 0.0;
+			uint32_t fpFor = 0u;
+			wave_vmem_sync(); // node records written by earlier expansions
+			if (ok && st != 0u && st != kExplored) {
+				const Node* fn = nodes + (st - 1u);
+				fpx = fn->x;
+				fpy = fn->y;
+				fpt = fn->t;
+				fptot = fn->totalCost;
+				fpFor = st;
+			}
+			if (base == 0) {
+				// probable next pop (head of the front buffer or of the heap) -> pfWord
+				int cand = -1;
+				if (frontCount > 0 && (heapSize == 0 || key_before(lane_read64(front.ckey, 0), lane_read(front.nseq, 0), heapTop.ckey, heapTop.nseq)))
+					cand = (int)lane_read(front.node, 0);
+				else if (heapSize > 0)
+					cand = (int)heapTop.node;
+				pfNode = cand;
+				pfDead = false;
+				if (cand >= 0 && lane < 24)
+					pfWord = reinterpret_cast<const uint32_t*>(nodes + cand)[lane];
+			}
 			// does an EARLIER valid child of this batch share my cell?  (then my prefetched state may be stale)
 			bool dup = false;
 			const int cnt = min(64, P - base);
@@ -463,6 +507,11 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 						const int fs = __ffsll((long long)hitf) - 1;
 						fp = { c_x[fs], c_y[fs], c_t[fs] };
 						ftotal = c_total[fs];
+					} else if (lane_read(fpFor, c) == cst) {
+						fp.x = __longlong_as_double((long long)lane_read64((unsigned long long)__double_as_longlong(fpx), c));
+						fp.y = __longlong_as_double((long long)lane_read64((unsigned long long)__double_as_longlong(fpy), c));
+						fp.t = __longlong_as_double((long long)lane_read64((unsigned long long)__double_as_longlong(fpt), c));
+						ftotal = __longlong_as_double((long long)lane_read64((unsigned long long)__double_as_longlong(fptot), c));
 					} else {
 						wave_vmem_sync();
 						const Node fn = nodes[fi];
@@ -471,6 +520,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 					}
 					const Pose cp = { c_x[c], c_y[c], c_t[c] };
 					if (identical_poses(fp, cp) && ftotal > ctotal) {
+						if (fi == pfNode)
+							pfDead = true;
 						if (lane == 0)
 							nodes[fi].dead = 1;
 						if (myNode == fi)
@@ -642,6 +693,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 						}
 						const Pose cp = { c_x[kRsSlot], c_y[kRsSlot], c_t[kRsSlot] };
 						if (identical_poses(fp, cp) && ftotal > c_total[kRsSlot]) {
+							if (fi == pfNode)
+								pfDead = true;
 							if (lane == 0)
 								nodes[fi].dead = 1;
 							if (myNode == fi)
