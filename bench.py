@@ -30,7 +30,7 @@ CHILD_BYTES = 143.0                # per expansion child
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="queries per GPU per step")
     ap.add_argument("--cells", type=int, default=1024)
@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--check-poses", type=int, default=1 << 26)
     ap.add_argument("--cpu-sample", type=int, default=192, help="queries timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3, help="independent batches kept in flight (one planner + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=4, help="independent batches kept in flight (one planner + HIP stream each)")
     args = ap.parse_args()
 
     import numpy as np

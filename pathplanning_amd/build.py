@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libpphip.so")
 SOURCES = ["pp_capi.hip", "pp_kernels_basic.hip", "pp_wavefront.hip", "pp_planner.hip", "pp_rrt.hip"]
-HEADERS = ["pp_internal.hpp", "pp_device.hpp", "pp_rs_device.hpp", "pp_search_device.hpp", os.path.join("..", "..", "include", "pp_hip.h")]
+HEADERS = ["pp_internal.hpp", "pp_device.hpp", "pp_rs_device.hpp", "pp_search_device.hpp", "pp_row_primitives.hpp", "pp_planner_rows.hpp", os.path.join("..", "..", "include", "pp_hip.h")]
 # -ffp-contract=off: no FMA contraction -- discrete outputs must match the CPU reference bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -71,8 +71,22 @@ def build_plugin_test(verbose=True):
     return out
 
 
+def build_row_test(verbose=True):
+    """tests/cpp/test_row_primitives.hip: GPU self-test of the DPP row primitives (run on the GPU box)."""
+    out = os.path.join(LIB_DIR, "test_row_primitives")
+    src = os.path.join(HERE, "..", "tests", "cpp", "test_row_primitives.hip")
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "pp_row_primitives.hpp"))):
+        return out
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O2", "-I", CSRC, "-I", os.path.join(HERE, "..", "include"), src, "-o", out]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
     print(build_pyplanning())
     print(build_plugin_test())
+    print(build_row_test())

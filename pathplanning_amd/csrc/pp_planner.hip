@@ -12,6 +12,7 @@
 // Results are bit-identical to the sequential reference as long as libm and OCML agree on
 // the discrete outcomes (cells, validity); continuous poses agree to ~1e-15.
 #include "pp_search_device.hpp"
+#include "pp_row_primitives.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -788,6 +789,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	}
 }
 
+#include "pp_planner_rows.hpp"
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -815,6 +818,10 @@ struct pp_planner {
 	DevResult* results = nullptr;
 	unsigned long long* prof = nullptr; // diagnostic phase cycles, [maxBatch][PH_COUNT]
 	bool profile = false;
+	unsigned long long* mtStates = nullptr; // [maxBatch][312] mt19937_64 engine state per query (row kernel)
+	int* nextQuery = nullptr;               // query counter of the persistent row kernel
+	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
+	bool rowsKernel = false;                // PP_SEARCH_ROWS=1 selects the four-queries-per-wave kernel (experimental)
 	double *dStarts = nullptr, *dGoals = nullptr;
 	uint64_t* dSeeds = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -831,7 +838,7 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
-	void* ptrs[] = { p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->mtStates, p->nextQuery, p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -955,6 +962,20 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 		const int resident = pph::wavefront_resident_blocks();
 		p->wfSlots = max_batch < resident ? max_batch : resident;
 	}
+	{
+		int perCu = 0, dev = 0;
+		hipDeviceProp_t prop;
+		p->searchWaves = 2048;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_hybrid_search_rows, 64, 0) == hipSuccess && perCu >= 1)
+			p->searchWaves = perCu * prop.multiProcessorCount;
+		// Four-queries-per-wave kernel: ~4x the expansions per issued instruction, but a single query advances ~1.4x
+		// slower, and a batch ends with its longest query (65k sequential expansions here), so with the few batches
+		// that fit in HBM at once it measured slower end to end (6.7k vs 7.9k plans/s).  Opt-in until the per-query
+		// buffers are pooled.
+		const char* env = getenv("PP_SEARCH_ROWS");
+		p->rowsKernel = env && env[0] == '1';
+	}
 	hipError_t e = hipSuccess;
 	auto alloc = [&](void** ptr, size_t bytes) {
 		if (e == hipSuccess)
@@ -964,6 +985,8 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 	alloc((void**)&p->costFields, B * (size_t)A.fieldElems * sizeof(float));
 	alloc((void**)&p->wfWorkspace, (size_t)p->wfBytesPerSlot * p->wfSlots);
 	alloc((void**)&p->wfError, 8);
+	alloc((void**)&p->mtStates, B * Mt64::N * sizeof(unsigned long long));
+	alloc((void**)&p->nextQuery, sizeof(int));
 	alloc((void**)&p->goalCells, B * 4);
 	alloc((void**)&p->nodes, B * N * sizeof(Node));
 	alloc((void**)&p->heaps, B * N * sizeof(HeapEntry));
@@ -1062,7 +1085,15 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
 			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->results, planner->prof);
-	else
+	else if (planner->rowsKernel) {
+		// four queries per wave, taken from a counter by a persistent grid (pp_planner_rows.hpp); key maps start zeroed
+		PP_HIP_TRY(hipMemsetAsync(planner->keymaps, 0, (size_t)n_queries * planner->args.ks.size() * sizeof(uint32_t), s));
+		PP_HIP_TRY(hipMemsetAsync(planner->nextQuery, 0, sizeof(int), s));
+		const int wavesWanted = (n_queries + kRowsPerWave - 1) / kRowsPerWave;
+		const int grid = wavesWanted < planner->searchWaves ? wavesWanted : planner->searchWaves;
+		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(grid), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
+			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->mtStates, planner->results, planner->nextQuery);
+	} else
 		hipLaunchKernelGGL(k_hybrid_search<false>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
 			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->results, planner->prof);
 	PP_HIP_TRY(hipGetLastError());

@@ -1,0 +1,700 @@
+// k_hybrid_search_rows -- the batched Hybrid-A* graph search with FOUR queries per wave.
+//
+// Included by pp_planner.hip (inside its anonymous namespace, after Node / SearchArgs / DevResult).
+//
+// Why: one expansion creates P = 10 children, so the one-query-per-wave kernel keeps 10 of 64 lanes busy, and its
+// time per expansion (~12 us) is the same with 64 queries on the GPU as with 4096 (measured): it is bound by the
+// instruction stream of a single wave (f64 sincos / Reeds-Shepp / collision march issued for 10 lanes) plus a chain
+// of dependent memory round trips, not by memory bandwidth.  Here a query owns one DPP row (16 lanes) and the wave
+// runs the expansions of four queries in lock step: the same instruction stream now carries four expansions.
+//   * everything the old kernel kept wave-uniform (open-list sizes, node counts, the popped node...) is held
+//     replicated in the 16 lanes of the row; control flow diverges only at row granularity, so DPP row operations
+//     and ds_bpermute always find their source lanes active;
+//   * the sorted front buffer of the open list is 16 entries per query (one per lane, shifted with DPP row_shr /
+//     row_shl); what falls off goes to the same 64-ary heap in HBM, popped by 16 lanes x 4 children each;
+//   * rows take queries from a device counter as they finish (query lengths differ by 100x), and leave when it runs
+//     dry, so the grid is persistent: min(ceil(n/4), resident waves) workgroups of one wave;
+//   * the Mersenne-Twister state of a query lives in HBM (2.5 KB per query, one 8-byte read per expansion).
+// Pop order, node numbering, RNG draws and every counter are identical to the one-query-per-wave kernel and to the
+// oracle (tests/test_gpu_hybrid.py checks the expanded sequence).
+#pragma once
+
+// --------------------------------------------------------------------------------------------------- kernel --
+__global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_rows(SearchArgs A, int nQueries, const double* __restrict__ starts,
+	const double* __restrict__ goals, const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase,
+	HeapEntry* __restrict__ heapBase, uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase,
+	unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery)
+{
+	const int lane = threadIdx.x;
+	const int rl = lane & (kRowLanes - 1);
+	const int sb = (lane >> 4) * kRowSlots; // first staging slot of this row
+
+	// staging of the children of the node being expanded (per row); kept until the next expansion so that a child popped
+	// right away is read back from LDS instead of HBM
+	constexpr int kS = kRowsPerWave * kRowSlots;
+	__shared__ double c_x[kS], c_y[kS], c_t[kS], c_cost[kS], c_total[kS], c_len[kS], c_h[kS], c_sin[kS], c_cos[kS];
+	__shared__ double f_x[kS], f_y[kS], f_t[kS], f_tot[kS]; // open-list node already in the child's cell (shortcut test)
+	__shared__ uint32_t c_key[kS], c_state[kS], f_for[kS];
+	__shared__ uint8_t c_flags[kS], c_valid[kS]; // flags: 1 = valid child, 2 = an earlier child of the batch shares its cell
+	__shared__ int16_t c_action[kS];
+	__shared__ int s_rsChecks[kRowsPerWave];
+	__shared__ HeapEntry s_spill[kRowsPerWave][kRowLanes];
+	HeapEntry* const spillBuf = s_spill[lane >> 4];
+
+	const MapView& m = A.m;
+	const int P = A.prims.n;
+	const int maxNodes = A.maxNodes;
+
+	// ---- per-row state (replicated in the row's lanes)
+	int q = -1;
+	bool act = false, done = false;
+	Node* nodes = nullptr;
+	HeapEntry* heap = nullptr;
+	uint32_t* keymap = nullptr;
+	unsigned long long* mt = nullptr;
+	const float* field = nullptr;
+	Pose goal = { 0, 0, 0 };
+	int myNode = -1, rsNode = -1;
+	int pfNode = -1;               // node whose record was prefetched as the probable next pop
+	unsigned long long pf64 = 0ull; // lane k < 11: 8-byte word k of that record
+	bool pfDead = false;           // it was replaced (ProcessPossibleShortcut) after the fetch
+	FrontLane front;
+	front_clear(front);
+	int frontCount = 0, heapSize = 0, nSpill = 0;
+	HeapEntry heapTop;
+	heapTop.ckey = ~0ull;
+	heapTop.nseq = ~0u;
+	heapTop.node = 0;
+	int nNodes = 0;
+	uint32_t seq = 0;
+	int mtIdx = 0;
+	int nExpanded = 0, nRngDraws = 0, nRsAttempts = 0, nRsLog = 0;
+	long long laneStateChecks = 0, lanePathChecks = 0, rsStateChecks = 0, rsPathChecks = 0;
+	int status = -1, solutionNode = -1;
+	double solutionCost = __builtin_huge_val();
+
+	auto flush_spills = [&]() { // row-uniform nSpill > 0
+		wave_lds_sync();
+		bool needSift = false;
+		HeapEntry mine;
+		mine.ckey = ~0ull;
+		mine.nseq = ~0u;
+		mine.node = 0;
+		if (rl < nSpill) {
+			mine = spillBuf[rl];
+			const int pos = heapSize + rl;
+			if (pos > 0) {
+				const int par = (pos - 1) >> 6;
+				if (par >= heapSize)
+					needSift = true; // a parent slot that is itself being appended in this flush
+				else {
+					const HeapEntry pe = heap[par];
+					needSift = heap_before(mine, pe);
+				}
+			}
+		}
+		if (row_bits(__ballot(needSift), lane)) {
+			if (rl == 0) {
+				int hs = heapSize;
+				for (int i = 0; i < nSpill; i++)
+					heap_push(heap, hs, spillBuf[i]);
+			}
+		} else if (rl < nSpill) {
+			heap[heapSize + rl] = mine;
+		}
+		for (int i = 0; i < nSpill; i++) {
+			const HeapEntry e = spillBuf[i];
+			if (heapSize + i == 0 || heap_before(e, heapTop))
+				heapTop = e;
+		}
+		heapSize += nSpill;
+		nSpill = 0;
+		wave_vmem_sync();
+	};
+	auto spill = [&](const HeapEntry& e) {
+		if (rl == 0)
+			spillBuf[nSpill] = e;
+		nSpill++;
+		if (nSpill == kRowLanes)
+			flush_spills();
+	};
+	auto finish = [&]() { // writes the result record of the row's query and frees the row
+		const long long nStateChecks = row_sum_i64(laneStateChecks, lane) + rsStateChecks;
+		const long long pathChecks = row_sum_i64(lanePathChecks, lane) + rsPathChecks;
+		wave_vmem_sync();
+		if (rl == 0) {
+			DevResult r;
+			r.r.status = status;
+			r.r.n_expanded = nExpanded;
+			r.r.n_nodes = nNodes;
+			r.r.n_path = 0;
+			if (status == 0) {
+				int depth = 0;
+				for (int k = solutionNode; k >= 0; k = nodes[k].parent)
+					depth++;
+				r.r.n_path = depth;
+			}
+			r.r.cost = solutionCost;
+			r.r.n_rng_draws = nRngDraws;
+			r.r.n_rs_attempts = nRsAttempts;
+			r.r.n_state_checks = nStateChecks;
+			r.r.n_path_checks = pathChecks;
+			r.solutionNode = solutionNode;
+			r.nRsLog = nRsLog < kRsLogCap ? nRsLog : kRsLogCap;
+			results[q] = r;
+		}
+		act = false;
+	};
+
+	for (;;) {
+		// ================= rows without a query take the next one =================
+		if (!act && !done) {
+			int nq = 0;
+			if (rl == 0)
+				nq = atomicAdd(nextQuery, 1);
+			q = (int)row_read((uint32_t)nq, lane, 0);
+			if (q >= nQueries) {
+				done = true;
+			} else {
+				nodes = nodesBase + (size_t)q * maxNodes;
+				heap = heapBase + (size_t)q * maxNodes;
+				keymap = keymapBase + (size_t)q * A.ks.size(); // zeroed by the host before the launch
+				mt = mtBase + (size_t)q * Mt64::N;
+				field = costFields + (size_t)q * A.fieldElems;
+				// goal / start poses go through the Pose2d constructor on the caller's side (theta wrapped)
+				const Pose start = { starts[3 * q], starts[3 * q + 1], wrap_theta(starts[3 * q + 2]) };
+				goal = { goals[3 * q], goals[3 * q + 1], wrap_theta(goals[3 * q + 2]) };
+				// ---- InitializeSearch, a_star.h:350-364
+				myNode = -1;
+				rsNode = -1;
+				pfNode = -1;
+				pfDead = false;
+				front_clear(front);
+				frontCount = 0;
+				heapSize = 0;
+				nSpill = 0;
+				heapTop.ckey = ~0ull;
+				heapTop.nseq = ~0u;
+				heapTop.node = 0;
+				nNodes = 1;
+				seq = 1;
+				nExpanded = nRngDraws = nRsAttempts = nRsLog = 0;
+				laneStateChecks = lanePathChecks = rsStateChecks = rsPathChecks = 0;
+				status = -1;
+				solutionNode = -1;
+				solutionCost = __builtin_huge_val();
+				if (rl == 0)
+					Mt64::seed(mt, seeds[q]);
+				mtIdx = Mt64::N; // engine freshly seeded: first draw twists
+				double rs_, rc_;
+				sincos(start.t, &rs_, &rc_);
+				int ix, iy, it;
+				discretize_pose(start, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+				uint32_t key = kNoKey;
+				const bool ok = A.ks.pack(ix, iy, it, key);
+				if (rl == 0) {
+					Node root;
+					root.x = start.x;
+					root.y = start.y;
+					root.t = start.t;
+					root.pathCost = 0.0;
+					root.totalCost = 0.0;
+					root.length = 0.0;
+					root.h = combined_heuristic_sc(A.heur, m, field, goal, start, rs_, rc_);
+					root.sinT = rs_;
+					root.cosT = rc_;
+					root.parent = -1;
+					root.key = ok ? key : kNoKey;
+					root.action = -1;
+					root.dead = 0;
+					nodes[0] = root;
+					if (ok)
+						keymap[key] = kExplored; // the root is inserted in the explored set at init (a_star.h:361)
+				}
+				HeapEntry e;
+				e.ckey = cost_key(0.0);
+				e.nseq = 0xFFFFFFFFu;
+				e.node = 0;
+				HeapEntry sp;
+				front_insert_row(front, frontCount, e, rl, lane, sp);
+				wave_vmem_sync();
+				act = true;
+			}
+		}
+		if (!__ballot(act))
+			break; // every row has run out of queries
+		if (!act)
+			continue;
+
+		// ================= one step of SearchPath's main loop (a_star.h:337-345) for every active row =================
+		if (!(frontCount > 0 || heapSize > 0 || nSpill > 0)) {
+			finish(); // open list exhausted: status stays -1
+			continue;
+		}
+		if (nSpill > 0)
+			flush_spills();
+		HeapEntry top;
+		const bool fromFront = frontCount > 0 && (heapSize == 0 || key_before(row_read64(front.ckey, lane, 0), row_read(front.nseq, lane, 0), heapTop.ckey, heapTop.nseq));
+		if (fromFront) {
+			top = front_pop_row(front, frontCount, lane);
+		} else {
+			wave_vmem_sync(); // earlier heap writes
+			top = heap_pop_row(heap, heapSize, rl, lane, heapTop);
+			wave_vmem_sync();
+		}
+		const int ni = (int)top.node;
+		// ---- the popped node: from the staging of the previous expansion when it is one of its children, else from the
+		// prefetch of the probable next pop, else from HBM
+		double px, py, pt, pPathCost, pH, pSin, pCos;
+		uint32_t pKey;
+		bool pDead = false;
+		{
+			const uint32_t hit = row_bits(__ballot(myNode == ni), lane);
+			const int slot = hit ? (__ffs((int)hit) - 1) : (rsNode == ni ? kRowRs : -1);
+			if (slot >= 0) {
+				px = c_x[sb + slot];
+				py = c_y[sb + slot];
+				pt = c_t[sb + slot];
+				pPathCost = c_cost[sb + slot];
+				pH = c_h[sb + slot];
+				pSin = c_sin[sb + slot];
+				pCos = c_cos[sb + slot];
+				pKey = c_key[sb + slot];
+			} else if (ni == pfNode) {
+				// lane k of the row holds the k-th 8-byte word of the record (see the prefetch below)
+				auto d64 = [&](int k) { return __longlong_as_double((long long)row_read64(pf64, lane, k)); };
+				px = d64(0);
+				py = d64(1);
+				pt = d64(2);
+				pPathCost = d64(3);
+				pH = d64(6);
+				pSin = d64(7);
+				pCos = d64(8);
+				pKey = (uint32_t)(row_read64(pf64, lane, 9) >> 32);                     // { parent, key }
+				pDead = pfDead || ((row_read64(pf64, lane, 10) >> 16) & 0xFFull) != 0ull; // { action, dead, pad }
+			} else {
+				const Node nd = nodes[ni];
+				px = nd.x;
+				py = nd.y;
+				pt = nd.t;
+				pPathCost = nd.pathCost;
+				pH = nd.h;
+				pSin = nd.sinT;
+				pCos = nd.cosT;
+				pKey = nd.key;
+				pDead = nd.dead != 0;
+			}
+		}
+		wave_lds_sync(); // staging is about to be overwritten
+		if (pDead)
+			continue; // entry of a node replaced by ProcessPossibleShortcut
+		const Pose ppose = { px, py, pt };
+		if (identical_poses(ppose, goal)) { // IsSolution, hybrid_a_star.h:193-196
+			status = 0;
+			solutionNode = ni;
+			solutionCost = pPathCost;
+			finish();
+			continue;
+		}
+		// ---- Expand, a_star.h:377-409
+		if (rl == 0) {
+			if (pKey != kNoKey)
+				keymap[pKey] = kExplored; // children in the parent's own cell are caught by a key compare below
+			(expandedBase + (size_t)q * maxNodes)[nExpanded] = (uint32_t)ni;
+		}
+		rsNode = -1;
+		nExpanded++;
+		int pix, piy, pit;
+		discretize_pose(ppose, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, pix, piy, pit);
+		const double hCost = pH; // RS gate input (hybrid_a_star.cpp:81): computed when the node was created
+		// the raw 64-bit draw the RS gate may need is fetched now (one word of the query's engine state in HBM)
+		unsigned long long mtRaw = 0ull;
+		const bool gateDraws = !(hCost < 10.0);
+		if (gateDraws && mtIdx < Mt64::N)
+			mtRaw = mt[mtIdx];
+
+		bool capacity = false;
+		// ---- constant-steer children, reference order p = 2*deltaIndex + direction (hybrid_a_star.cpp:65-77)
+		for (int base = 0; base < P && !capacity; base += kRowLanes) {
+			const int p = base + rl;
+			bool ok = false;
+			uint32_t key = kNoKey, st = 0u;
+			Pose child = ppose;
+			double cs = pSin, cc = pCos;
+			double gcost = 0.0, total = 0.0, len = 0.0, hh = 0.0;
+			if (p < P) {
+				ArcSC a;
+				a.init = ppose;
+				a.sinF = pSin;
+				a.cosF = pCos;
+				a.kappa = A.prims.kappa[p];
+				a.length = A.rp.arcLength;
+				a.backward = A.prims.backward[p];
+				child = a.interpolate_sc(1.0, cs, cc);
+				int ix, iy, it;
+				discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+				// look-ups of the full-length child are issued before the validity march so that their latency
+				// overlaps it (they are redone only when the arc gets truncated)
+				bool packed = A.ks.pack(ix, iy, it, key);
+				if (packed)
+					st = keymap[key];
+				hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
+				// Voronoi term of the full-length arc: its only map read (the last sample, Q8) is issued with the look-ups
+				const double voroFull = voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
+				float lastValidRatio;
+				int checks = 0;
+				ok = true;
+				lanePathChecks++;
+				const bool pathValid = is_path_valid(m, a, a.init, lastValidRatio, checks);
+				if (!pathValid) {
+					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
+					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
+					a.length *= (double)lastValidRatio;
+					discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+					if (ix == pix && iy == piy && it == pit)
+						ok = false;
+					else {
+						packed = A.ks.pack(ix, iy, it, key);
+						if (packed)
+							st = keymap[key];
+						hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
+					}
+				}
+				laneStateChecks += checks;
+				if (ok) {
+					const double pathCost = (a.backward ? A.rp.reverseMult : A.rp.forwardMult) * a.length;
+					const double voro = pathValid ? voroFull : voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
+					const double cost = pathCost + 0.0 + voro; // switching cost is always 0 (hybrid_a_star.cpp:142)
+					len = a.length;
+					gcost = pPathCost + cost;
+					total = gcost + hh; // a_star.h:387-388
+					if (!packed)
+						ok = false; // outside the key map (cannot happen for poses inside the bounds)
+				}
+			}
+			if (ok && key == pKey)
+				st = kExplored; // the parent's cell was marked explored just above (a_star.h:381)
+			// open-list node already in this child's cell: its pose / cost (needed by ProcessPossibleShortcut) is fetched by
+			// the child's own lane, all lanes at once, instead of one dependent load per child in the loop below
+			double fpx = 0.0, fpy = 0.0, fpt = 0.0, fptot = 0.0;
+			uint32_t fpFor = 0u;
+			wave_vmem_sync(); // node records written by earlier expansions
+			if (ok && st != 0u && st != kExplored) {
+				const Node* fn = nodes + (st - 1u);
+				fpx = fn->x;
+				fpy = fn->y;
+				fpt = fn->t;
+				fptot = fn->totalCost;
+				fpFor = st;
+			}
+			if (base == 0) {
+				// probable next pop (head of the front buffer or of the heap): lane k < 11 fetches 8-byte word k of its record
+				int cand = -1;
+				if (frontCount > 0 && (heapSize == 0 || key_before(row_read64(front.ckey, lane, 0), row_read(front.nseq, lane, 0), heapTop.ckey, heapTop.nseq)))
+					cand = (int)row_read(front.node, lane, 0);
+				else if (heapSize > 0)
+					cand = (int)heapTop.node;
+				pfNode = cand;
+				pfDead = false;
+				if (cand >= 0 && rl < 11)
+					pf64 = reinterpret_cast<const unsigned long long*>(nodes + cand)[rl];
+			}
+			// does an EARLIER valid child of this batch share my cell?  (then my prefetched state may be stale)
+			const bool dup = row_earlier_same(key, ok, rl);
+			// staging: read by the insertion loop below and by the pop that follows
+			c_key[sb + rl] = key;
+			c_state[sb + rl] = st;
+			c_flags[sb + rl] = (uint8_t)((ok ? 1 : 0) | (dup ? 2 : 0));
+			c_x[sb + rl] = child.x;
+			c_y[sb + rl] = child.y;
+			c_t[sb + rl] = child.t;
+			c_cost[sb + rl] = gcost;
+			c_total[sb + rl] = total;
+			c_len[sb + rl] = len;
+			c_h[sb + rl] = hh;
+			c_sin[sb + rl] = cs;
+			c_cos[sb + rl] = cc;
+			f_x[sb + rl] = fpx;
+			f_y[sb + rl] = fpy;
+			f_t[sb + rl] = fpt;
+			f_tot[sb + rl] = fptot;
+			f_for[sb + rl] = fpFor;
+			myNode = -1;
+			wave_lds_sync();
+			// ---- insertion in child order (a_star.h:391-402 + hybrid_a_star.h:199-205): the four rows walk their
+			// children c = 0, 1, ... together
+			const int cnt = min(kRowLanes, P - base);
+			for (int c = 0; c < cnt; c++) {
+				const uint32_t flags = c_flags[sb + c];
+				if (!(flags & 1u) || capacity)
+					continue;
+				const uint32_t ckey = c_key[sb + c];
+				uint32_t cst = c_state[sb + c];
+				if (flags & 2u) {
+					wave_vmem_sync(); // lane 0's key-map writes of this batch
+					cst = keymap[ckey];
+				}
+				const double ctotal = c_total[sb + c];
+				bool push = false;
+				if (cst == 0u) {
+					push = true; // !inFrontier && !inExplored
+				} else if (cst != kExplored) {
+					// in the open list: replace only if the poses are identical and the new path is strictly cheaper
+					const int fi = (int)cst - 1;
+					const uint32_t hitf = row_bits(__ballot(myNode == fi), lane);
+					Pose fp;
+					double ftotal;
+					if (hitf) {
+						const int fs = __ffs((int)hitf) - 1;
+						fp = { c_x[sb + fs], c_y[sb + fs], c_t[sb + fs] };
+						ftotal = c_total[sb + fs];
+					} else if (f_for[sb + c] == cst) {
+						fp = { f_x[sb + c], f_y[sb + c], f_t[sb + c] };
+						ftotal = f_tot[sb + c];
+					} else {
+						wave_vmem_sync();
+						const Node fn = nodes[fi];
+						fp = { fn.x, fn.y, fn.t };
+						ftotal = fn.totalCost;
+					}
+					const Pose cp = { c_x[sb + c], c_y[sb + c], c_t[sb + c] };
+					if (identical_poses(fp, cp) && ftotal > ctotal) {
+						if (fi == pfNode)
+							pfDead = true;
+						if (rl == 0)
+							nodes[fi].dead = 1;
+						if (myNode == fi)
+							myNode = -1; // its staged copy must not be used any more
+						push = true;
+					}
+				}
+				if (push) {
+					if (nNodes >= maxNodes) {
+						capacity = true;
+						continue;
+					}
+					const int idx = nNodes++;
+					if (rl == c)
+						myNode = idx;
+					if (rl == 0)
+						keymap[ckey] = (uint32_t)idx + 1u;
+					HeapEntry e;
+					e.ckey = cost_key(ctotal);
+					e.nseq = 0xFFFFFFFFu - seq;
+					seq++;
+					e.node = (uint32_t)idx;
+					HeapEntry sp;
+					if (front_insert_row(front, frontCount, e, rl, lane, sp))
+						spill(sp);
+				}
+			}
+			// ---- every lane writes the node record of its own child
+			if (myNode >= 0) {
+				Node nd;
+				nd.x = child.x;
+				nd.y = child.y;
+				nd.t = child.t;
+				nd.pathCost = gcost;
+				nd.totalCost = total;
+				nd.length = len;
+				nd.h = hh;
+				nd.sinT = cs;
+				nd.cosT = cc;
+				nd.parent = ni;
+				nd.key = key;
+				nd.action = (int16_t)p;
+				nd.dead = 0;
+				nodes[myNode] = nd;
+			}
+		}
+		if (capacity) {
+			status = -4;
+			finish();
+			continue;
+		}
+
+		// ---- Reeds-Shepp analytic expansion, gated (hybrid_a_star.cpp:81-88): the RNG is drawn only when hCost >= 10
+		// (short-circuit ||)
+		bool tryRs = !gateDraws;
+		if (gateDraws) {
+			if (mtIdx >= Mt64::N) {
+				wave_vmem_sync();
+				mt_twist_row(mt, rl);
+				mtIdx = 0;
+				mtRaw = mt[0];
+			}
+			const double u = Mt64::uniform01(Mt64::temper(mtRaw));
+			mtIdx++;
+			nRngDraws++;
+			tryRs = u < 10.0 / (hCost * hCost);
+		}
+		if (tryRs) {
+			nRsAttempts++;
+			// GetOptimalPath (reeds_shepp.cpp:654-683): lane l evaluates words l, l + 16, l + 32
+			Pose rel;
+			{
+				// goal - start (geometry/2dplane.h:65-79) with the stored sin/cos of the node's heading
+				const double dx = goal.x - ppose.x, dy = goal.y - ppose.y;
+				const double s = -pSin, c = pCos;
+				rel.x = c * dx + (-s) * dy;
+				rel.y = s * dx + c * dy;
+				rel.t = wrap_theta(wrap_theta(goal.t - ppose.t));
+			}
+			rel.x = rel.x / A.rmin;
+			rel.y = rel.y / A.rmin;
+			float wcost = __builtin_huge_valf();
+			int wword = 0x7FFFFFFF;
+			double wt = 0, wu = 0, wv = 0;
+			for (int k = 0; k < rs::kNumWords / kRowLanes; k++) {
+				const int w = rl + kRowLanes * k;
+				double gx, gy, gt, t_, u_, v_;
+				rs::goal_variant(rel, w % 4, gx, gy, gt);
+				const double length = rs::base_lengths(w / 4, gx, gy, gt, t_, u_, v_);
+				if (!(length == rs::inf())) {
+					rs::Segment sg;
+					rs::word_segment(w, t_, u_, v_, sg);
+					const float cst = rs::compute_cost(sg, A.rmin, A.rsRev, A.rsFwd, A.rsSw);
+					// NaN and +inf never win a `cost < optimalCost` test; words ascend, so the first strict minimum is kept
+					if (cst < __builtin_huge_valf() && cst < wcost) {
+						wcost = cst;
+						wword = w;
+						wt = t_;
+						wu = u_;
+						wv = v_;
+					}
+				}
+			}
+			// first strictly-lowest float cost in word order (costs are >= 0: their bit patterns order like the values)
+			const uint32_t bestBits = row_min_u32(__float_as_uint(wcost));
+			const bool mine = wword != 0x7FFFFFFF && __float_as_uint(wcost) == bestBits;
+			const uint32_t wsel = row_min_u32(mine ? (uint32_t)wword : 0xFFFFFFFFu);
+			const int word = wsel == 0xFFFFFFFFu ? -1 : (int)wsel;
+			if (word >= 0) {
+				const int owner = word & (kRowLanes - 1);
+				const double bt = row_read_f64(wt, lane, owner), bu = row_read_f64(wu, lane, owner), bv = row_read_f64(wv, lane, owner);
+				// the winner's path is validated by one lane (the adaptive march is sequential)
+				if (rl == 0) {
+					rs::Path path;
+					path.init = ppose;
+					rs::word_segment(word, bt, bu, bv, path.seg);
+					path.rmin = A.rmin;
+					path.length = path.seg.length * A.rmin; // PathSegment::GetLength
+					float lastRatio;
+					int checks = 0;
+					const bool valid = is_path_valid(m, path, path.init, lastRatio, checks);
+					c_valid[sb + kRowRs] = 0;
+					s_rsChecks[lane >> 4] = checks;
+					if (valid) {
+						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
+						const Pose child = path.interpolate(1.0);
+						int ix, iy, it;
+						discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+						const double voro = voronoi_cost(m, path, A.rp.voroDiagRes, A.rp.voronoiMult);
+						const double cost = pathAndSwitchingCosts + voro;
+						uint32_t key;
+						if (A.ks.pack(ix, iy, it, key)) {
+							double s_, c_;
+							sincos(child.t, &s_, &c_);
+							const double hh = combined_heuristic_sc(A.heur, m, field, goal, child, s_, c_);
+							c_valid[sb + kRowRs] = 1;
+							c_key[sb + kRowRs] = key;
+							c_x[sb + kRowRs] = child.x;
+							c_y[sb + kRowRs] = child.y;
+							c_t[sb + kRowRs] = child.t;
+							c_cost[sb + kRowRs] = pPathCost + cost;
+							c_total[sb + kRowRs] = (pPathCost + cost) + hh;
+							c_len[sb + kRowRs] = path.length;
+							c_h[sb + kRowRs] = hh;
+							c_sin[sb + kRowRs] = s_;
+							c_cos[sb + kRowRs] = c_;
+							c_state[sb + kRowRs] = keymap[key];
+							c_action[sb + kRowRs] = (int16_t)(1000 + word);
+						}
+					}
+				}
+				wave_lds_sync();
+				rsPathChecks++;
+				rsStateChecks += (long long)s_rsChecks[lane >> 4];
+				if (c_valid[sb + kRowRs]) {
+					const uint32_t ckey = c_key[sb + kRowRs];
+					const uint32_t cst = c_state[sb + kRowRs];
+					bool push = false;
+					if (cst == 0u)
+						push = true;
+					else if (cst != kExplored) {
+						const int fi = (int)cst - 1;
+						const uint32_t hitf = row_bits(__ballot(myNode == fi), lane);
+						Pose fp;
+						double ftotal;
+						if (hitf) {
+							const int fs = __ffs((int)hitf) - 1;
+							fp = { c_x[sb + fs], c_y[sb + fs], c_t[sb + fs] };
+							ftotal = c_total[sb + fs];
+						} else {
+							wave_vmem_sync();
+							const Node fn = nodes[fi];
+							fp = { fn.x, fn.y, fn.t };
+							ftotal = fn.totalCost;
+						}
+						const Pose cp = { c_x[sb + kRowRs], c_y[sb + kRowRs], c_t[sb + kRowRs] };
+						if (identical_poses(fp, cp) && ftotal > c_total[sb + kRowRs]) {
+							if (fi == pfNode)
+								pfDead = true;
+							if (rl == 0)
+								nodes[fi].dead = 1;
+							if (myNode == fi)
+								myNode = -1;
+							push = true;
+						}
+					}
+					if (push) {
+						if (nNodes >= maxNodes) {
+							status = -4;
+							finish();
+							continue;
+						}
+						const int idx = nNodes++;
+						if (rl == 0) {
+							Node nd;
+							nd.x = c_x[sb + kRowRs];
+							nd.y = c_y[sb + kRowRs];
+							nd.t = c_t[sb + kRowRs];
+							nd.pathCost = c_cost[sb + kRowRs];
+							nd.totalCost = c_total[sb + kRowRs];
+							nd.length = c_len[sb + kRowRs];
+							nd.h = c_h[sb + kRowRs];
+							nd.sinT = c_sin[sb + kRowRs];
+							nd.cosT = c_cos[sb + kRowRs];
+							nd.parent = ni;
+							nd.key = ckey;
+							nd.action = c_action[sb + kRowRs];
+							nd.dead = 0;
+							nodes[idx] = nd;
+							keymap[ckey] = (uint32_t)idx + 1u;
+							if (nRsLog < kRsLogCap) {
+								RsLogEntry le;
+								le.node = idx;
+								le.word = word;
+								le.t = bt;
+								le.u = bu;
+								le.v = bv;
+								(rsLogBase + (size_t)q * kRsLogCap)[nRsLog] = le;
+							}
+						}
+						rsNode = idx;
+						nRsLog++;
+						HeapEntry e;
+						e.ckey = cost_key(c_total[sb + kRowRs]);
+						e.nseq = 0xFFFFFFFFu - seq;
+						seq++;
+						e.node = (uint32_t)idx;
+						HeapEntry sp;
+						if (front_insert_row(front, frontCount, e, rl, lane, sp))
+							spill(sp);
+					}
+				}
+				wave_lds_sync();
+			}
+		}
+	}
+}

@@ -274,26 +274,30 @@ PPD_INLINE void front_clear(FrontLane& f)
 }
 PPD_INLINE bool key_before(unsigned long long ak, unsigned int as, unsigned long long bk, unsigned int bs) { return ak < bk || (ak == bk && as < bs); }
 
+#ifndef PP_FRONT_CAP
+#define PP_FRONT_CAP 64 // entries of the open list kept in registers (tuning experiments: 16 / 32)
+#endif
 /// Inserts e (wave-uniform).  Returns true when an entry left the buffer (written to `spilled`).
 PPD_INLINE bool front_insert(FrontLane& f, int& count, const HeapEntry& e, int lane, HeapEntry& spilled)
 {
+	constexpr int kCap = PP_FRONT_CAP;
 	const bool mineFirst = lane < count && key_before(f.ckey, f.nseq, e.ckey, e.nseq);
 	const int pos = __popcll(__ballot(mineFirst));
-	if (pos >= 64) {
+	if (pos >= kCap) {
 		spilled = e;
 		return true;
 	}
 	bool spill = false;
-	if (count == 64) {
-		spilled.ckey = lane_read64(f.ckey, 63);
-		spilled.nseq = lane_read(f.nseq, 63);
-		spilled.node = lane_read(f.node, 63);
+	if (count == kCap) {
+		spilled.ckey = lane_read64(f.ckey, kCap - 1);
+		spilled.nseq = lane_read(f.nseq, kCap - 1);
+		spilled.node = lane_read(f.node, kCap - 1);
 		spill = true;
 	}
 	const unsigned long long uk = wave_shr1_64(f.ckey, ~0ull);
 	const unsigned int us = wave_shr1(f.nseq, ~0u);
 	const unsigned int un = wave_shr1(f.node, 0u);
-	if (lane > pos) {
+	if (lane > pos && lane < kCap) {
 		f.ckey = uk;
 		f.nseq = us;
 		f.node = un;
@@ -302,7 +306,7 @@ PPD_INLINE bool front_insert(FrontLane& f, int& count, const HeapEntry& e, int l
 		f.nseq = e.nseq;
 		f.node = e.node;
 	}
-	if (count < 64)
+	if (count < kCap)
 		count++;
 	return spill;
 }

@@ -119,3 +119,32 @@ def test_node_capacity_is_reported():
     planner.initialize()
     res = planner.search_batch([[-11.0, -11.0, 0.0]], [[11.0, 11.0, 0.0]], [1])
     assert res[0].status == -4
+
+
+def test_four_queries_per_wave_kernel_parity(monkeypatch):
+    """PP_SEARCH_ROWS=1: the experimental kernel with one query per 16-lane row (pp_planner_rows.hpp) must walk
+    exactly the same expansions -- including P > 16 primitives (two child batches per expansion)."""
+    monkeypatch.setenv("PP_SEARCH_ROWS", "1")
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    rng = np.random.RandomState(21)
+    n = 21  # not a multiple of 4: the last wave has idle rows
+    starts = valid_random_poses(rng, w, n)
+    goals = valid_random_poses(rng, w, n)
+    goals[2] = starts[2]
+    goals[3] = [100.0, 0.0, 0.0]
+    seeds = np.arange(n, dtype=np.uint64) + 7
+    planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds)
+    assert compare(planner, res, h, starts, goals, seeds) >= n // 2
+    kw = dict(num_generated_motion=9, reverse_cost_multiplier=2.0, direction_switching_cost=0.3, voronoi_cost_multiplier=0.5)
+    planner, res, h = run_pair(w, ms, val, kw, starts[:6], goals[:6], seeds[:6], max_nodes=65536)
+    compare(planner, res, h, starts[:6], goals[:6], seeds[:6])
+
+
+def test_row_primitives_selftest():
+    """DPP row shifts / butterflies / bpermute reads used by the four-queries-per-wave kernel, against scalar loops."""
+    import subprocess
+    from pathplanning_amd import build
+    exe = build.build_row_test(verbose=False)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "row primitives OK" in out.stdout
