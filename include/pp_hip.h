@@ -157,6 +157,14 @@ int64_t pp_obstacle_heuristic_workspace_bytes(pp_map* map);
  * algo/heuristics.cpp:78-95,155-165; utils/frontier.h).  One independent query per
  * (start, goal, seed); seed reseeds the query's own mt19937_64 (utils/random.h). */
 int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, pp_planner** out);
+/* Same with an explicit number of search rows.  Planners sized for throughput (max_batch > 64) run the graph search
+ * four queries per wave on a persistent grid whose rows take queries from a counter; node / heap / key-map buffers
+ * exist per ROW, not per query.  search_rows = 0: as many rows as can be resident on the device (or max_batch if
+ * smaller); callers that keep several planners in flight on one GPU pass resident rows / planners. */
+int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, int32_t search_rows,
+	pp_planner** out);
+/* Rows the planner's search runs with (k_hybrid_search_rows); 0 = the one-query-per-wave kernel (k_hybrid_search). */
+int pp_planner_search_rows(pp_planner* planner);
 int pp_planner_destroy(pp_planner* planner);
 /* Uses a table built elsewhere (host pointer), or builds it on the device when NULL. */
 int pp_planner_set_nonholo_table(pp_planner* planner, const double* table_host);

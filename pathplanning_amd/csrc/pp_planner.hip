@@ -36,6 +36,15 @@ struct Node { // 96 bytes
 };
 static_assert(sizeof(Node) == 96, "Node layout");
 
+/// One node of a solution path, written by the search kernel when the query ends (goal first, root last): the node
+/// records themselves live in per-slot buffers that the next query of the slot overwrites.
+struct PathRec {
+	double x, y, t, length;
+	int32_t action; // Node::action
+	int32_t node;   // node index (matches RsLogEntry::node)
+};
+static_assert(sizeof(PathRec) == 40, "PathRec layout");
+
 struct RsLogEntry {
 	int32_t node, word;
 	double t, u, v;
@@ -72,6 +81,7 @@ struct SearchArgs {
 	double rmin;
 	float rsRev, rsFwd, rsSw; // Reeds-Shepp cost weights as floats (reeds_shepp.cpp:654)
 	int maxNodes;
+	int maxPath; // PathRec entries per query
 	size_t cells;
 	int64_t fieldElems; // floats per query in costFields (8 x 8-tiled obstacle-heuristic field)
 };
@@ -113,6 +123,29 @@ __device__ __forceinline__ void wave_vmem_sync()
 	__builtin_amdgcn_wave_barrier();
 }
 
+/// GetPath (a_star.h:254-288): walks the parent chain from the solution node; records are written goal first.
+/// Returns the number of nodes on the path (it may exceed `cap`: only the first `cap` records are stored).
+__device__ inline int write_path(const Node* nodes, int solutionNode, PathRec* out, int cap)
+{
+	int depth = 0;
+	for (int k = solutionNode; k >= 0;) {
+		const Node nd = nodes[k];
+		if (depth < cap) {
+			PathRec pr;
+			pr.x = nd.x;
+			pr.y = nd.y;
+			pr.t = nd.t;
+			pr.length = nd.length;
+			pr.action = nd.action;
+			pr.node = k;
+			out[depth] = pr;
+		}
+		depth++;
+		k = nd.parent;
+	}
+	return depth;
+}
+
 enum { PH_POP = 0, PH_LOAD, PH_HEUR, PH_CHILD, PH_DUP, PH_INSERT, PH_WRITE, PH_RS, PH_COUNT };
 constexpr int kSlots = 65; // staging: one slot per lane + one for the Reeds-Shepp child
 constexpr int kRsSlot = 64;
@@ -123,8 +156,8 @@ constexpr int kRsSlot = 64;
 template <bool kProfile>
 __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(SearchArgs A, int nQueries, const double* __restrict__ starts, const double* __restrict__ goals,
 	const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase, HeapEntry* __restrict__ heapBase,
-	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, DevResult* __restrict__ results,
-	unsigned long long* __restrict__ prof)
+	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, PathRec* __restrict__ pathBase,
+	DevResult* __restrict__ results, unsigned long long* __restrict__ prof)
 {
 	const int q = blockIdx.x;
 	if (q >= nQueries)
@@ -360,7 +393,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		if (lane == 0) {
 			if (pKey != kNoKey)
 				keymap[pKey] = kExplored; // children in the parent's own cell are caught by a key compare below
-			expanded[nExpanded] = (uint32_t)ni;
+			expanded[nExpanded] = pKey; // the expansion log holds the packed discrete pose of each expanded node
 		}
 		rsNode = -1;
 		nExpanded++;
@@ -772,12 +805,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		r.r.n_expanded = nExpanded;
 		r.r.n_nodes = nNodes;
 		r.r.n_path = 0;
-		if (status == 0) {
-			int depth = 0;
-			for (int k = solutionNode; k >= 0; k = nodes[k].parent)
-				depth++;
-			r.r.n_path = depth;
-		}
+		if (status == 0)
+			r.r.n_path = write_path(nodes, solutionNode, pathBase + (size_t)q * A.maxPath, A.maxPath);
 		r.r.cost = solutionCost;
 		r.r.n_rng_draws = nRngDraws;
 		r.r.n_rs_attempts = nRsAttempts;
@@ -818,10 +847,13 @@ struct pp_planner {
 	DevResult* results = nullptr;
 	unsigned long long* prof = nullptr; // diagnostic phase cycles, [maxBatch][PH_COUNT]
 	bool profile = false;
-	unsigned long long* mtStates = nullptr; // [maxBatch][312] mt19937_64 engine state per query (row kernel)
-	int* nextQuery = nullptr;               // query counter of the persistent row kernel
+	unsigned long long* mtStates = nullptr; // [searchRows][312] mt19937_64 engine state per row (rows kernel)
+	int* nextQuery = nullptr;               // query counter of the persistent rows kernel
 	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
-	bool rowsKernel = false;                // PP_SEARCH_ROWS=1 selects the four-queries-per-wave kernel (experimental)
+	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
+	bool rowsKernel = false;                // four-queries-per-wave kernel (throughput) vs one query per wave (latency)
+	PathRec* paths = nullptr;               // [maxBatch][maxPath] solution paths, goal first
+	int maxPath = 0;
 	double *dStarts = nullptr, *dGoals = nullptr;
 	uint64_t* dSeeds = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -838,7 +870,7 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
-	void* ptrs[] = { p->mtStates, p->nextQuery, p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->paths, p->mtStates, p->nextQuery, p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -858,7 +890,12 @@ extern "C" {
 
 int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, pp_planner** out)
 {
-	if (!map || !params || !out || max_batch < 1 || max_nodes_per_query < 16) {
+	return pp_planner_create_ex(map, params, max_batch, max_nodes_per_query, 0, out);
+}
+
+int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, int32_t search_rows, pp_planner** out)
+{
+	if (!map || !params || !out || max_batch < 1 || max_nodes_per_query < 16 || search_rows < 0) {
 		set_error("invalid arguments");
 		return PP_ERR_INVALID;
 	}
@@ -934,6 +971,8 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 	A.rsFwd = (float)params->forward_cost_multiplier;
 	A.rsSw = (float)params->direction_switching_cost;
 	A.maxNodes = max_nodes_per_query;
+	A.maxPath = max_nodes_per_query < 2048 ? max_nodes_per_query : 2048;
+	p->maxPath = A.maxPath;
 	A.cells = map->cells();
 	A.fieldElems = (int64_t)field_tiled_elems(map->desc.rows, map->desc.cols);
 	// key space: every discrete pose a state inside the bounds (plus one arc of slack) can take
@@ -969,12 +1008,21 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
 			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_hybrid_search_rows, 64, 0) == hipSuccess && perCu >= 1)
 			p->searchWaves = perCu * prop.multiProcessorCount;
-		// Four-queries-per-wave kernel: ~4x the expansions per issued instruction, but a single query advances ~1.4x
-		// slower, and a batch ends with its longest query (65k sequential expansions here), so with the few batches
-		// that fit in HBM at once it measured slower end to end (6.7k vs 7.9k plans/s).  Opt-in until the per-query
-		// buffers are pooled.
+		// Which search kernel?  The four-queries-per-wave kernel (pp_planner_rows.hpp) issues ~4x fewer instructions per
+		// expansion and needs node/heap/key-map buffers only for its resident rows, so many batches fit in HBM at once;
+		// the one-query-per-wave kernel advances a single query ~1.4x faster.  Throughput-sized planners take the
+		// former, small ones (the plugin's single-query path) the latter.  PP_SEARCH_ROWS=0/1 forces either.
 		const char* env = getenv("PP_SEARCH_ROWS");
-		p->rowsKernel = env && env[0] == '1';
+		p->rowsKernel = env && (env[0] == '0' || env[0] == '1') ? env[0] == '1' : max_batch > 64;
+		// rows (= buffer slots) of the persistent grid: as many as can be resident, unless the caller shares the GPU
+		// between several planners (bench.py: resident rows / batches in flight)
+		int rows = p->searchWaves * kRowsPerWave;
+		if (search_rows > 0 && search_rows < rows)
+			rows = search_rows;
+		const int wanted = (max_batch + kRowsPerWave - 1) / kRowsPerWave * kRowsPerWave;
+		if (wanted < rows)
+			rows = wanted;
+		p->searchRows = (rows + kRowsPerWave - 1) / kRowsPerWave * kRowsPerWave;
 	}
 	hipError_t e = hipSuccess;
 	auto alloc = [&](void** ptr, size_t bytes) {
@@ -985,13 +1033,16 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 	alloc((void**)&p->costFields, B * (size_t)A.fieldElems * sizeof(float));
 	alloc((void**)&p->wfWorkspace, (size_t)p->wfBytesPerSlot * p->wfSlots);
 	alloc((void**)&p->wfError, 8);
-	alloc((void**)&p->mtStates, B * Mt64::N * sizeof(unsigned long long));
+	// search buffers: one set per resident row (rows kernel) or per query (one-query-per-wave kernel)
+	const size_t S = p->rowsKernel ? (size_t)p->searchRows : B;
+	alloc((void**)&p->mtStates, (p->rowsKernel ? S : 1) * Mt64::N * sizeof(unsigned long long));
 	alloc((void**)&p->nextQuery, sizeof(int));
 	alloc((void**)&p->goalCells, B * 4);
-	alloc((void**)&p->nodes, B * N * sizeof(Node));
-	alloc((void**)&p->heaps, B * N * sizeof(HeapEntry));
-	alloc((void**)&p->keymaps, B * A.ks.size() * 4);
+	alloc((void**)&p->nodes, S * N * sizeof(Node));
+	alloc((void**)&p->heaps, S * N * sizeof(HeapEntry));
+	alloc((void**)&p->keymaps, S * A.ks.size() * 4);
 	alloc((void**)&p->expanded, B * N * 4);
+	alloc((void**)&p->paths, B * (size_t)A.maxPath * sizeof(PathRec));
 	alloc((void**)&p->rsLogs, B * kRsLogCap * sizeof(RsLogEntry));
 	alloc((void**)&p->results, B * sizeof(DevResult));
 	alloc((void**)&p->prof, B * PH_COUNT * sizeof(unsigned long long));
@@ -1082,20 +1133,20 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, planner->goalCells, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
 		planner->wfError, nullptr, /*tiledOut=*/true));
 	PP_HIP_TRY(hipEventRecord(planner->e1, s));
-	if (planner->profile)
-		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->results, planner->prof);
-	else if (planner->rowsKernel) {
-		// four queries per wave, taken from a counter by a persistent grid (pp_planner_rows.hpp); key maps start zeroed
-		PP_HIP_TRY(hipMemsetAsync(planner->keymaps, 0, (size_t)n_queries * planner->args.ks.size() * sizeof(uint32_t), s));
+	if (planner->rowsKernel) {
+		// four queries per wave, taken from a counter by a persistent grid (pp_planner_rows.hpp)
 		PP_HIP_TRY(hipMemsetAsync(planner->nextQuery, 0, sizeof(int), s));
 		const int wavesWanted = (n_queries + kRowsPerWave - 1) / kRowsPerWave;
-		const int grid = wavesWanted < planner->searchWaves ? wavesWanted : planner->searchWaves;
+		const int wavesMax = planner->searchRows / kRowsPerWave;
+		const int grid = wavesWanted < wavesMax ? wavesWanted : wavesMax;
 		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(grid), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
-			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->mtStates, planner->results, planner->nextQuery);
-	} else
+			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, planner->nextQuery);
+	} else if (planner->profile)
+		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof);
+	else
 		hipLaunchKernelGGL(k_hybrid_search<false>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->results, planner->prof);
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof);
 	PP_HIP_TRY(hipGetLastError());
 	PP_HIP_TRY(hipEventRecord(planner->e2, s));
 	planner->lastBatch = n_queries;
@@ -1145,10 +1196,16 @@ int pp_planner_search_batch(pp_planner* planner, int32_t n_queries, const double
 	return pp_planner_fetch_results(planner, n_queries, results_host);
 }
 
+int pp_planner_search_rows(pp_planner* planner) { return planner && planner->rowsKernel ? planner->searchRows : 0; }
+
 int pp_planner_set_profiling(pp_planner* planner, int32_t enable)
 {
 	if (!planner) {
 		set_error("null planner");
+		return PP_ERR_INVALID;
+	}
+	if (enable && planner->rowsKernel) {
+		set_error("phase profiling exists for the one-query-per-wave kernel only: create the planner with PP_SEARCH_ROWS=0");
 		return PP_ERR_INVALID;
 	}
 	planner->profile = enable != 0;
@@ -1189,35 +1246,36 @@ int pp_planner_get_path(pp_planner* planner, int32_t q, double* poses_host, int3
 	if (r.r.status != 0 || r.solutionNode < 0)
 		return PP_OK; // empty path
 	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
-	const int nNodes = r.r.n_nodes;
-	std::vector<Node> nodes(nNodes);
-	PP_HIP_TRY(hipMemcpy(nodes.data(), planner->nodes + (size_t)q * planner->maxNodes, (size_t)nNodes * sizeof(Node), hipMemcpyDeviceToHost));
+	const int n = r.r.n_path;
+	if (n > planner->maxPath) {
+		set_error("solution path longer than the planner's path buffer");
+		return PP_ERR_CAPACITY;
+	}
+	std::vector<PathRec> recs(n); // goal first (write_path)
+	if (n)
+		PP_HIP_TRY(hipMemcpy(recs.data(), planner->paths + (size_t)q * planner->maxPath, (size_t)n * sizeof(PathRec), hipMemcpyDeviceToHost));
 	std::vector<RsLogEntry> rslog(r.nRsLog);
 	if (r.nRsLog)
 		PP_HIP_TRY(hipMemcpy(rslog.data(), planner->rsLogs + (size_t)q * kRsLogCap, (size_t)r.nRsLog * sizeof(RsLogEntry), hipMemcpyDeviceToHost));
-	std::vector<int> chain;
-	for (int k = r.solutionNode; k >= 0; k = nodes[k].parent)
-		chain.push_back(k);
-	for (size_t i = 0; i < chain.size(); i++) {
-		const Node& n = nodes[chain[chain.size() - 1 - i]];
-		const int idx = chain[chain.size() - 1 - i];
+	for (int i = 0; i < n; i++) {
+		const PathRec& nd = recs[n - 1 - i];
 		if (poses_host) {
-			poses_host[3 * i] = n.x;
-			poses_host[3 * i + 1] = n.y;
-			poses_host[3 * i + 2] = n.t;
+			poses_host[3 * i] = nd.x;
+			poses_host[3 * i + 1] = nd.y;
+			poses_host[3 * i + 2] = nd.t;
 		}
-		const int kind = n.action < 0 ? 0 : (n.action >= 1000 ? 2 : 1);
+		const int kind = nd.action < 0 ? 0 : (nd.action >= 1000 ? 2 : 1);
 		if (kind_host)
 			kind_host[i] = kind;
 		if (prim_host)
-			prim_host[i] = kind == 2 ? n.action - 1000 : n.action;
+			prim_host[i] = kind == 2 ? nd.action - 1000 : nd.action;
 		if (length_host)
-			length_host[i] = n.length;
+			length_host[i] = nd.length;
 		if (tuv_host) {
 			tuv_host[3 * i] = tuv_host[3 * i + 1] = tuv_host[3 * i + 2] = 0.0;
 			if (kind == 2)
 				for (const auto& le : rslog)
-					if (le.node == idx) {
+					if (le.node == nd.node) {
 						tuv_host[3 * i] = le.t;
 						tuv_host[3 * i + 1] = le.u;
 						tuv_host[3 * i + 2] = le.v;
@@ -1238,16 +1296,13 @@ int pp_planner_get_expanded(pp_planner* planner, int32_t q, int32_t* cells_host)
 	const int ne = r.r.n_expanded;
 	if (ne == 0)
 		return PP_OK;
-	std::vector<uint32_t> idx(ne);
-	PP_HIP_TRY(hipMemcpy(idx.data(), planner->expanded + (size_t)q * planner->maxNodes, (size_t)ne * 4, hipMemcpyDeviceToHost));
-	std::vector<Node> nodes(r.r.n_nodes);
-	PP_HIP_TRY(hipMemcpy(nodes.data(), planner->nodes + (size_t)q * planner->maxNodes, (size_t)r.r.n_nodes * sizeof(Node), hipMemcpyDeviceToHost));
+	std::vector<uint32_t> keys(ne); // packed discrete pose of every expanded node, in expansion order
+	PP_HIP_TRY(hipMemcpy(keys.data(), planner->expanded + (size_t)q * planner->maxNodes, (size_t)ne * 4, hipMemcpyDeviceToHost));
 	const KeySpace& ks = planner->args.ks;
 	for (int i = 0; i < ne; i++) {
-		const Node& n = nodes[idx[i]];
 		int ix = 0, iy = 0, it = 0;
-		if (n.key != kNoKey)
-			ks.unpack(n.key, ix, iy, it);
+		if (keys[i] != kNoKey)
+			ks.unpack(keys[i], ix, iy, it);
 		cells_host[3 * i] = ix;
 		cells_host[3 * i + 1] = iy;
 		cells_host[3 * i + 2] = it;

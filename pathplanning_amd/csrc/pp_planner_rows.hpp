@@ -23,11 +23,18 @@
 __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_rows(SearchArgs A, int nQueries, const double* __restrict__ starts,
 	const double* __restrict__ goals, const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase,
 	HeapEntry* __restrict__ heapBase, uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase,
-	unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery)
+	PathRec* __restrict__ pathBase, unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery)
 {
 	const int lane = threadIdx.x;
 	const int rl = lane & (kRowLanes - 1);
 	const int sb = (lane >> 4) * kRowSlots; // first staging slot of this row
+	// search buffers (node records, heap, key map, engine state) belong to the ROW, not to the query: the row's
+	// queries use them one after the other, so a planner needs them for its resident rows only
+	const size_t slot = (size_t)blockIdx.x * kRowsPerWave + (size_t)(lane >> 4);
+	Node* const nodes = nodesBase + slot * A.maxNodes;
+	HeapEntry* const heap = heapBase + slot * A.maxNodes;
+	uint32_t* const keymap = keymapBase + slot * A.ks.size();
+	unsigned long long* const mt = mtBase + slot * Mt64::N;
 
 	// staging of the children of the node being expanded (per row); kept until the next expansion so that a child popped
 	// right away is read back from LDS instead of HBM
@@ -48,10 +55,6 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	// ---- per-row state (replicated in the row's lanes)
 	int q = -1;
 	bool act = false, done = false;
-	Node* nodes = nullptr;
-	HeapEntry* heap = nullptr;
-	uint32_t* keymap = nullptr;
-	unsigned long long* mt = nullptr;
 	const float* field = nullptr;
 	Pose goal = { 0, 0, 0 };
 	int myNode = -1, rsNode = -1;
@@ -128,12 +131,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			r.r.n_expanded = nExpanded;
 			r.r.n_nodes = nNodes;
 			r.r.n_path = 0;
-			if (status == 0) {
-				int depth = 0;
-				for (int k = solutionNode; k >= 0; k = nodes[k].parent)
-					depth++;
-				r.r.n_path = depth;
-			}
+			if (status == 0)
+				r.r.n_path = write_path(nodes, solutionNode, pathBase + (size_t)q * A.maxPath, A.maxPath);
 			r.r.cost = solutionCost;
 			r.r.n_rng_draws = nRngDraws;
 			r.r.n_rs_attempts = nRsAttempts;
@@ -156,11 +155,21 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			if (q >= nQueries) {
 				done = true;
 			} else {
-				nodes = nodesBase + (size_t)q * maxNodes;
-				heap = heapBase + (size_t)q * maxNodes;
-				keymap = keymapBase + (size_t)q * A.ks.size(); // zeroed by the host before the launch
-				mt = mtBase + (size_t)q * Mt64::N;
 				field = costFields + (size_t)q * A.fieldElems;
+				{ // the slot's key map still holds the previous query of this row
+					const size_t n = A.ks.size(), n4 = n / 4;
+					const uint4 z = { 0, 0, 0, 0 };
+					if ((((uintptr_t)keymap) & 15) == 0) {
+						for (size_t i = rl; i < n4; i += kRowLanes)
+							reinterpret_cast<uint4*>(keymap)[i] = z;
+						for (size_t i = n4 * 4 + rl; i < n; i += kRowLanes)
+							keymap[i] = 0;
+					} else {
+						for (size_t i = rl; i < n; i += kRowLanes)
+							keymap[i] = 0;
+					}
+					wave_vmem_sync();
+				}
 				// goal / start poses go through the Pose2d constructor on the caller's side (theta wrapped)
 				const Pose start = { starts[3 * q], starts[3 * q + 1], wrap_theta(starts[3 * q + 2]) };
 				goal = { goals[3 * q], goals[3 * q + 1], wrap_theta(goals[3 * q + 2]) };
@@ -300,7 +309,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 		if (rl == 0) {
 			if (pKey != kNoKey)
 				keymap[pKey] = kExplored; // children in the parent's own cell are caught by a key compare below
-			(expandedBase + (size_t)q * maxNodes)[nExpanded] = (uint32_t)ni;
+			(expandedBase + (size_t)q * maxNodes)[nExpanded] = pKey; // packed discrete pose of the expanded node
 		}
 		rsNode = -1;
 		nExpanded++;

@@ -8,25 +8,29 @@
 //     in the open list, every cell whose cost is < fl(L + 1) is ALREADY in the open list:
 //     the "window" of this round.
 //   * the reference pops the window in the order (cost ascending, push order descending);
-//     a bitonic sort gives each window cell its rank i.
+//     a rank sort gives each window cell its rank i.
 //   * popping cell i pushes its undiscovered neighbours in the fixed enumeration order
 //     j = 0..7 (utils/grid.cpp:29-47).  A neighbour n is discovered by the smallest (i, j)
 //     that reaches it; the winner writes cost = cost_i + edge (same f32 add as the
-//     reference) and the push order roundBase + i*8 + j, monotone in the reference's push time.
+//     reference) and is appended to the open list at its place in the reference's push order.
 //
-// What bounds this kernel (measured, profiles/r01_wavefront_*): not HBM bytes but the per-CU
-// rate of uncoalesced cache-line requests -- window cells are ordered by cost, not by position,
-// so every lane touches its own line.  The layout therefore minimises REQUESTS per cell:
-//   * working grid = padded (rows+2) x (cols+2) f32 costs; occupied cells and the border hold
-//     a NaN pattern, undiscovered cells +inf: one 12-byte row load yields occupancy AND
-//     discovery state of three neighbours (3 requests per 3x3 neighbourhood, no bounds tests);
-//   * discovery claims of a round are resolved in an LDS hash table (cell -> min (i*8+j)) with
-//     LDS atomics -- no global traffic -- whenever the window fits (w <= 2048);
-//   * (cost - L, ~pushOrder, cell) is packed into ONE 64-bit key, so the sort moves 8 B/element.
-// Larger windows fall back to publishing (round, rank) per cell and gathering the seven other
-// neighbours of n (exact, atomic-free, more requests); windows beyond LDS sort in HBM.
-// One workgroup per goal.  Algorithmic bytes: 9 B/cell.
+// Layout and mechanics (measured history in DESIGN.md 4.3 and profiles/r01_wavefront_*):
+//   * the open list is a SEQUENCE in push order (8-byte entries cost | row,col), kept in LDS while it has
+//     <= 4096 entries, else ping-pong in HBM; stable compaction by ballots + a DPP scan, appends by a block
+//     scan of win counts -- position in the list replaces an explicit push-order field;
+//   * window entries are packed into ONE 64-bit key (cost - L : 23 | ~position : 19 | row,col : 22) and
+//     ranked by a bucketed counting sort in LDS (7 LDS-only barriers);
+//   * discovery claims of a round are resolved in an LDS hash table (cell -> min (i*8+j)) whenever the
+//     window fits (w <= 2048); larger windows publish (round, rank) per cell and gather the seven other
+//     neighbours of n (exact, atomic-free), windows beyond LDS sort in HBM;
+//   * state = one byte per cell (free / occupied+border / discovered) in 8 x 8 tiles of one cache line: a
+//     3 x 3 neighbourhood is three 8-byte loads; the cost is stored once, at discovery, into the output field
+//     (8 x 8-tiled for the search kernel, row-major for the public entry points);
+//   * barriers that only order LDS traffic do not drain outstanding global stores.
+// One workgroup per goal, two per CU.  Algorithmic bytes: 9 B/cell.
 #include "pp_internal.hpp"
+
+#include <cstdlib>
 
 using namespace ppd;
 

@@ -327,7 +327,10 @@ class HybridAStarBatch:
         planner.set_init_state(pose); planner.set_goal_state(pose); planner.search_path(); planner.get_path()
     """
 
-    def __init__(self, validator, params=None, max_batch=1, max_nodes=16384):
+    def __init__(self, validator, params=None, max_batch=1, max_nodes=16384, search_rows=0):
+        """search_rows: rows (= node/heap/key-map buffer sets) of the four-queries-per-wave search kernel that
+        throughput-sized planners (max_batch > 64) use; 0 = as many as can be resident.  Pass resident rows / k when k
+        planners share one GPU."""
         self.validator = validator
         self.map = validator.map
         self.lib = self.map.lib
@@ -335,9 +338,10 @@ class HybridAStarBatch:
         self.cparams = self.params.to_c()
         self.max_batch, self.max_nodes = int(max_batch), int(max_nodes)
         h = C.c_void_p()
-        check(self.lib.pp_planner_create(self.map.h, C.byref(self.cparams), self.max_batch, self.max_nodes, C.byref(h)))
+        check(self.lib.pp_planner_create_ex(self.map.h, C.byref(self.cparams), self.max_batch, self.max_nodes, int(search_rows), C.byref(h)))
         self.h = h
         self.num_primitives = self.lib.pp_planner_num_primitives(self.h)
+        self.search_rows = self.lib.pp_planner_search_rows(self.h)  # 0: one-query-per-wave kernel
         self._init = np.zeros(3)
         self._goal = np.zeros(3)
         self._seed = 0

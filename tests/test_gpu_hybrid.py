@@ -11,10 +11,10 @@ from gpu_common import make_pair, valid_random_poses
 pytestmark = pytest.mark.gpu
 
 
-def run_pair(w, ms, val, params_kw, starts, goals, seeds, max_nodes=32768, table=None, alias=True, negk=True):
+def run_pair(w, ms, val, params_kw, starts, goals, seeds, max_nodes=32768, table=None, alias=True, negk=True, search_rows=0):
     import pathplanning_amd as pa
     P = pa.HybridAStarSearchParameters(heading_alias=alias, negative_k_read=negk, **params_kw)
-    planner = pa.HybridAStarBatch(val, P, max_batch=len(starts), max_nodes=max_nodes)
+    planner = pa.HybridAStarBatch(val, P, max_batch=len(starts), max_nodes=max_nodes, search_rows=search_rows)
     planner.initialize(table)
     res = planner.search_batch(starts, goals, seeds)
     h = O.Hybrid(w, O.params_array(**params_kw), heading_alias=alias, negative_k_read=negk, table=planner.nonholo_table())
@@ -138,6 +138,24 @@ def test_four_queries_per_wave_kernel_parity(monkeypatch):
     kw = dict(num_generated_motion=9, reverse_cost_multiplier=2.0, direction_switching_cost=0.3, voronoi_cost_multiplier=0.5)
     planner, res, h = run_pair(w, ms, val, kw, starts[:6], goals[:6], seeds[:6], max_nodes=65536)
     compare(planner, res, h, starts[:6], goals[:6], seeds[:6])
+
+
+def test_search_rows_are_reused_by_successive_queries(monkeypatch):
+    """A throughput-sized planner (max_batch > 64 selects the rows kernel by itself) with only 8 rows: every row runs
+    ~9 queries one after the other in the same node / heap / key-map buffers; results, expansion logs and paths (copied
+    out by the kernel when a query ends) must still be the oracle's."""
+    monkeypatch.delenv("PP_SEARCH_ROWS", raising=False)
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    rng = np.random.RandomState(31)
+    n = 70
+    starts = valid_random_poses(rng, w, n)
+    goals = valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 1000
+    planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=8)
+    assert compare(planner, res, h, starts, goals, seeds) >= n // 2
+    # the same planner again: buffers of the previous batch are recycled
+    res2 = planner.search_batch(starts[::-1].copy(), goals[::-1].copy(), seeds[::-1].copy())
+    assert [r.n_expanded for r in res2] == [r.n_expanded for r in res][::-1]
 
 
 def test_row_primitives_selftest():
