@@ -61,9 +61,10 @@ __host__ __device__ inline int64_t padded_cells(int rows, int cols) { return (in
 __host__ __device__ inline int64_t round256(int64_t b) { return (b + 255) / 256 * 256; }
 /// byte address of padded cell (pr, pcc) in the tiled state grid
 __device__ __forceinline__ uint32_t st_addr(int tpr, int pr, int pcc) { return ((uint32_t)((pr >> 3) * tpr + (pcc >> 3)) << 6) | (uint32_t)(((pr & 7) << 3) | (pcc & 7)); }
-// cells travel as (padded row << 16 | padded col); the packed window key holds them in 22 bits (11 + 11)
-__device__ __forceinline__ uint32_t pack22(uint32_t cell) { return ((cell >> 16) << 11) | (cell & 0x7FFu); }
-__device__ __forceinline__ uint32_t unpack22(uint32_t k) { return ((k >> 11) << 16) | (k & 0x7FFu); }
+// cells travel as (padded row << 16 | padded col); the packed window key holds them in 2 * cb bits (cb = 11 for grids
+// up to 2045 x 2045, else 13)
+__device__ __forceinline__ uint32_t pack_cell(uint32_t cell, int cb) { return ((cell >> 16) << cb) | (cell & 0xFFFFu); }
+__device__ __forceinline__ uint32_t unpack_cell(uint32_t k, int cb) { return ((k >> cb) << 16) | (k & ((1u << cb) - 1u)); }
 
 __device__ __forceinline__ WfSlot slot_view(void* base, int64_t bytesPerSlot, int slot, int64_t stBytes, int64_t pcells, uint32_t fcap, uint32_t gcap)
 {
@@ -388,7 +389,7 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v)
 /// histogram into bucket offsets, and only members of the same bucket are compared with each other (equal costs
 /// are common -- symmetric cells -- so buckets hold a handful of keys).  Seven barriers, all LDS-only.
 /// hist must be all zero on entry and is all zero again on exit.
-__device__ __forceinline__ void rank_sort(uint64_t* skey, uint32_t* hist, uint32_t* wsum, uint32_t w, uint32_t range)
+__device__ __forceinline__ void rank_sort(uint64_t* skey, uint32_t* hist, uint32_t* wsum, uint32_t w, uint32_t range, int shiftD)
 {
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -406,7 +407,7 @@ __device__ __forceinline__ void rank_sort(uint64_t* skey, uint32_t* hist, uint32
 	for (int u = 0; u < 8; u++) {
 		const uint32_t i = (uint32_t)(tid + u * WF_T);
 		if (i < w) {
-			const uint32_t bkt = (uint32_t)(k[u] >> 41) >> shift;
+			const uint32_t bkt = (uint32_t)(k[u] >> shiftD) >> shift; // shiftD: position of (cost - L) in the key
 			const uint32_t arr = atomicAdd(&hist[bkt], 1u);
 			meta[u] = bkt | (arr << 11);
 		}
@@ -498,7 +499,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 	const int64_t pcells = padded_cells(rows, cols);
 	const int64_t stBytes = state_bytes(rows, cols);
 	const int64_t fieldElems = tiledOut ? (int64_t)field_tiled_elems(rows, cols) : cells; // floats per goal in costOut
-	const bool packable = rows + 2 <= 2047 && cols + 2 <= 2047; // (row, col) fits the 22 cell bits of the packed window key
+	// packed window key = (cost - L) | ~position : pb | (row, col) : 2 cb; pb = 12 while the list is in LDS, else 19
+	const bool packable = rows + 2 <= 8191 && cols + 2 <= 8191;
+	const int cb = (rows + 2 <= 2047 && cols + 2 <= 2047) ? 11 : 13;
+	const uint32_t cellMask = (1u << (2 * cb)) - 1u;
 	WfSlot S = slot_view(workspace, bytesPerSlot, blockIdx.x, stBytes, pcells, fcap, gcap);
 	uint8_t* const state = S.state;
 	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
@@ -586,6 +590,9 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			const int par = (int)(round & 1u);
 			const float L = __uint_as_float(lBits);
 			const uint32_t hiBits = __float_as_uint(L + 1.0f);
+			const int pb = inLds ? 12 : 19;
+			const int shiftD = pb + 2 * cb; // (cost - L) has 64 - shiftD bits: >= 23 unless cb = 13 in HBM mode (19)
+			const uint32_t posMask = (1u << pb) - 1u;
 			WF_STAMP(WP_MIN);
 			// ---- partition: window (cost < fl(L+1)) -> sort buffer; the rest stays in the open list IN ORDER.
 			// The list is kept in push order, so "pushed later" == "further back": a window entry is packed as
@@ -622,7 +629,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					const bool inW = i < n && c < hiBits;
 					if (inW) {
 						const uint32_t wslot = (off >> 16) + (uint32_t)__popcll(bw[u] & ltMask);
-						skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0x7FFFFu - i) << 22) | (uint64_t)pack22(cell);
+						skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << shiftD) | ((uint64_t)(posMask - i) << (2 * cb)) | (uint64_t)pack_cell(cell, cb);
 					} else if (i < n) {
 						const uint32_t rslot = (off & 0xFFFFu) + (uint32_t)__popcll(br[u] & ltMask);
 						lent[rslot] = e[u];
@@ -660,10 +667,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 							if (inW) {
 								const uint32_t wslot = wRun + (off >> 16) + (uint32_t)__popcll(bw[u] & ltMask);
 								if (fast) {
-									if (!packable || i >= (1u << 19) || (c - lBits) >= (1u << 23))
+									if (!packable || i > posMask || (uint64_t)(c - lBits) >= (1ull << (64 - shiftD)))
 										s_packFail = 1;
 									if (wslot < (uint32_t)WF_LCAP)
-										skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << 41) | ((uint64_t)(0x7FFFFu - (i & 0x7FFFFu)) << 22) | (uint64_t)(pack22(cell) & 0x3FFFFFu);
+										skey[SK((int)wslot)] = ((uint64_t)(c - lBits) << shiftD) | ((uint64_t)(posMask - (i & posMask)) << (2 * cb)) | (uint64_t)(pack_cell(cell, cb) & cellMask);
 								} else if (wslot < S.gcap) {
 									S.gkeys[wslot] = ((uint64_t)c << 32) | (uint64_t)(0xFFFFFFFFu - i);
 									S.gvals[wslot] = cell;
@@ -700,7 +707,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			}
 			if (fast) {
 				if (w > 1)
-					rank_sort(skey, hist, s_wsum, w, hiBits - lBits);
+					rank_sort(skey, hist, s_wsum, w, hiBits - lBits, shiftD);
 			} else {
 				const uint32_t P = w <= 1 ? 2 : (1u << (32 - __clz((int)(w - 1))));
 				__syncthreads();
@@ -739,8 +746,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					const uint32_t i = tid + q * WF_T;
 					if (i < w) {
 						const uint64_t k = skey[SK((int)i)];
-						myCell[q] = unpack22((uint32_t)k & 0x3FFFFFu);
-						myCost[q] = lBits + (uint32_t)(k >> 41);
+						myCell[q] = unpack_cell((uint32_t)k & cellMask, cb);
+						myCost[q] = lBits + (uint32_t)(k >> shiftD);
 					}
 				}
 				__syncthreads(); // the state bytes stored by the previous round are visible from here on
@@ -889,7 +896,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				__syncthreads();
 				const uint32_t roundTag = (round + 1u) << 17;
 				for (uint32_t i = tid; i < w; i += WF_T) {
-					const uint32_t cell = fast ? unpack22((uint32_t)skey[SK((int)i)] & 0x3FFFFFu) : S.gvals[i];
+					const uint32_t cell = fast ? unpack_cell((uint32_t)skey[SK((int)i)] & cellMask, cb) : S.gvals[i];
 					S.tag[tag_index(cell)] = roundTag | i;
 				}
 				__syncthreads();
@@ -902,8 +909,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					if (i < w) {
 						if (fast) {
 							const uint64_t k = skey[SK((int)i)];
-							cell = unpack22((uint32_t)k & 0x3FFFFFu);
-							cbits = lBits + (uint32_t)(k >> 41);
+							cell = unpack_cell((uint32_t)k & cellMask, cb);
+							cbits = lBits + (uint32_t)(k >> shiftD);
 						} else {
 							cell = S.gvals[i];
 							cbits = (uint32_t)(S.gkeys[i] >> 32);

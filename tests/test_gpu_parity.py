@@ -262,3 +262,59 @@ def test_tree_fixture_cases(env256):
     assert idx[0, 0] == tc["nearest"]["expect_index"]
     idx, _ = tree.get_nearest_nodes(tc["points"], [tc["knn"]["query"]], tc["knn"]["k"])
     assert set(idx[0]) == set(tc["knn"]["expect_indices_set"])
+
+
+def test_obstacle_heuristic_1024_large_windows():
+    """1024 x 1024 with few obstacles: rings of 4-6 k cells -- the open list leaves LDS, windows beyond 2048 cells take
+    the gather path, windows beyond 4096 the HBM sort.  Field must still equal the sequential reference order."""
+    import pathplanning_amd as pa
+    w, ms, val, ctx = make_pair(1024, 6, 5)
+    goals = [(0.0, 0.0), (-51.0, 50.9), (20.3, -35.1)]
+    got = pa.ObstaclesHeuristic(ms).update(goals)
+    for i, g in enumerate(goals):
+        cost, _ = w.obstacle_heuristic(g)
+        assert np.array_equal(got[i], cost), i
+
+
+def test_obstacle_heuristic_tall_grid_unpacked_keys():
+    """2200 x 40 cells: (row, col) needs 13 + 13 bits in the packed window key (the layout a 4096 x 4096 map uses)."""
+    import pathplanning_amd as pa
+    w = O.World(110.0, 2.0, 0.1)
+    assert w.rows == 2200 and w.cols == 40
+    rng = np.random.RandomState(10)
+    occ = np.full((w.rows, w.cols), -1, dtype=np.int32)
+    occ[rng.rand(w.rows, w.cols) < 0.15] = 0
+    w.set_occ(occ)
+    w.set_d2(np.full((w.rows, w.cols), 100, dtype=np.int32))
+    ctx = pa.Context(0)
+    ms = pa.OccupancyMapSet.from_bounds(ctx, w.lb, w.ub, 0.1)
+    ms.upload_occupancy(occ)
+    goals = [(0.05, 0.05), (-100.0, 1.0)]
+    got = pa.ObstaclesHeuristic(ms).update(goals)
+    for i, g in enumerate(goals):
+        cost, _ = w.obstacle_heuristic(g)
+        assert np.array_equal(got[i], cost), i
+
+
+def test_obstacle_heuristic_4096_map():
+    """BASELINE config 5 grid size: one goal on a 4096 x 4096 map (16.7 M cells, rings of 10-20 k cells: 13-bit cell
+    coordinates, open list in HBM, windows beyond the LDS sort buffer)."""
+    import pathplanning_amd as pa
+    w = O.World(204.8, 204.8, 0.1)
+    assert w.rows == 4096 and w.cols == 4096
+    rng = np.random.RandomState(2)
+    occ = np.full((w.rows, w.cols), -1, dtype=np.int32)
+    for _ in range(96):  # box outlines with one open side, a few hundred cells across
+        r0, c0 = rng.randint(100, 3600, 2)
+        h, wd = rng.randint(60, 400, 2)
+        occ[r0:r0 + h, c0] = 0
+        occ[r0:r0 + h, c0 + wd] = 0
+        occ[r0, c0:c0 + wd] = 0
+    w.set_occ(occ)
+    ctx = pa.Context(0)
+    ms = pa.OccupancyMapSet.from_bounds(ctx, w.lb, w.ub, 0.1)
+    ms.upload_occupancy(occ)
+    goal = (37.3, -101.2)
+    got = pa.ObstaclesHeuristic(ms).update([goal])[0]
+    cost, _ = w.obstacle_heuristic(goal)
+    assert np.array_equal(got, cost)
