@@ -163,6 +163,10 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
  * smaller); callers that keep several planners in flight on one GPU pass resident rows / planners. */
 int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, int32_t search_rows,
 	pp_planner** out);
+/* Diagnostics: the search tree of query q in creation order (parent index, pose, {pathCost, totalCost}, replaced flag);
+ * available while node records are kept per query (one-query-per-wave kernel).  Any pointer may be NULL. */
+int pp_planner_debug_nodes(pp_planner* planner, int32_t q, int32_t max_nodes, int32_t* parents_host, double* poses_host, double* costs_host,
+	int32_t* dead_host);
 /* Rows the planner's search runs with (k_hybrid_search_rows); 0 = the one-query-per-wave kernel (k_hybrid_search). */
 int pp_planner_search_rows(pp_planner* planner);
 int pp_planner_destroy(pp_planner* planner);

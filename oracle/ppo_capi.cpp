@@ -483,6 +483,21 @@ void ppo_hybrid_result_expanded(void* hv, int* cells3)
 		cells3[3 * i + 2] = h->last.expanded[i].theta;
 	}
 }
+/// Every node of the search tree in creation order: parent index, pose (3), {pathCost, totalCost}, dead flag.
+void ppo_hybrid_nodes(void* hv, int* parents, double* poses, double* costs, int* dead)
+{
+	auto* h = (HybridHandle*)hv;
+	for (size_t i = 0; i < h->algo->nodes.size(); i++) {
+		const HybridNode& n = h->algo->nodes[i];
+		parents[i] = n.parent;
+		poses[3 * i] = n.pose.x;
+		poses[3 * i + 1] = n.pose.y;
+		poses[3 * i + 2] = n.pose.theta;
+		costs[2 * i] = n.pathCost;
+		costs[2 * i + 1] = n.totalCost;
+		dead[i] = n.dead ? 1 : 0;
+	}
+}
 /// Per path node: pose (3), kind, steering, length, direction, rsWord, pathCost.
 void ppo_hybrid_result_path(void* hv, double* poses, int* kind, double* steering, double* length, int* direction, int* rsWord, double* pathCost)
 {

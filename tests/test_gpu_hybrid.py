@@ -166,3 +166,41 @@ def test_row_primitives_selftest():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "row primitives OK" in out.stdout
+
+
+def test_config5_4096_map_queries():
+    """BASELINE config 5 scale: 4096 x 4096 cells (409.6 m), non-holonomic table 411 x 411 x 73 built on the device,
+    obstacle heuristic on the 16.7 M-cell grid, RS analytic expansion on.  Distances come from an exact EDT here (the
+    distance grid is an input of the path; any consistent grid pins parity)."""
+    import pathplanning_amd as pa
+    from scipy import ndimage
+    w = O.World(204.8, 204.8, 0.1)
+    rng = np.random.RandomState(5)
+    occ = np.full((w.rows, w.cols), -1, dtype=np.int32)
+    for _ in range(60):
+        r0, c0 = rng.randint(200, 3500, 2)
+        h, wd = rng.randint(80, 400, 2)
+        occ[r0:r0 + h, c0] = 0
+        occ[r0, c0:c0 + wd] = 0
+    d = ndimage.distance_transform_edt(occ != 0)
+    d2 = np.minimum(np.rint(d * d), 2 ** 30).astype(np.int32)
+    w.set_occ(occ)
+    w.set_d2(d2)
+    w.set_pathcost(np.zeros((w.rows, w.cols), dtype=np.float32))
+    ctx = pa.Context(0)
+    ms = pa.OccupancyMapSet.from_bounds(ctx, w.lb, w.ub, 0.1)
+    ms.upload_dist2(d2)
+    ms.upload_occupancy(occ)
+    ms.upload_path_cost(np.zeros((w.rows, w.cols), dtype=np.float32))
+    val = pa.StateValidatorOccupancyMap(ms)
+    # (not on lattice boundaries: a goal at exact multiples of the 1 m spatial resolution makes the cell of the RS child
+    # -- PathReedsShepp's m_final = Interpolate(1.0), path_reeds_shepp.cpp:9 -- depend on the last ulp of sin/cos)
+    starts = np.array([[-150.3, -150.2, 0.3], [10.4, 20.7, -2.0], [180.6, -170.1, 1.0]])
+    goals = np.array([[-120.7, -100.4, 1.2], [60.37, 45.21, 0.5], [150.3, -120.6, 2.0]])
+    ok_s = w.is_state_valid(starts)
+    ok_g = w.is_state_valid(goals)
+    assert ok_s.all() and ok_g.all()
+    seeds = np.array([1, 2, 3], dtype=np.uint64)
+    planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, max_nodes=65536)
+    assert planner.nonholo_table().shape[:2] == (411, 411)
+    assert compare(planner, res, h, starts, goals, seeds) >= 2
