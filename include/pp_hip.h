@@ -226,6 +226,9 @@ typedef struct pp_rrt_result {
 typedef struct pp_rrt pp_rrt;
 int pp_rrt_run(pp_ctx* ctx, pp_map* map, const double lower[2], const double upper[2], const double params[4], const double init[2],
 	const double goal[2], uint64_t seed, int32_t star, pp_rrt** out, pp_rrt_result* result);
+/* n independent problems (own start, goal, seed) on the same map and parameters, one workgroup each, run together. */
+int pp_rrt_run_batch(pp_ctx* ctx, pp_map* map, const double lower[2], const double upper[2], const double params[4], int32_t n_problems,
+	const double* inits_xy, const double* goals_xy, const uint64_t* seeds, int32_t star, pp_rrt** outs, pp_rrt_result* results);
 int pp_rrt_get(pp_rrt* r, double* nodes_xy, int32_t* parents, double* costs, double* path_xy);
 int pp_rrt_destroy(pp_rrt* r);
 

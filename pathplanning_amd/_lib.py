@@ -114,6 +114,7 @@ def load():
     L.pp_knn.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, C.c_int32, vp, vp]
     L.pp_knn_dev.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, C.c_int32, vp, vp]
     L.pp_rrt_run.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_int32, C.POINTER(vp), C.POINTER(RrtResult)]
+    L.pp_rrt_run_batch.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, C.c_int32, C.POINTER(vp), C.POINTER(RrtResult)]
     L.pp_rrt_get.argtypes = [vp, vp, vp, vp, vp]
     L.pp_rrt_destroy.argtypes = [vp]
     _lib = L

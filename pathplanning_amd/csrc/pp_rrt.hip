@@ -4,17 +4,22 @@
 // The planners are strictly sequential (sample i sees the tree after i-1 insertions), so one
 // workgroup owns one tree and runs the whole loop on the device: no host round trip per sample.
 //   * the sample stream is the query's own mt19937_64 (utils/random.h), drawn on the device;
-//   * nearest / k-nearest = block-wide brute-force scan of the tree's points (double2, coalesced;
-//     1.6 MB at 1e5 nodes: L2 resident), squared L2 in double, ties -> lower node index;
+//   * nearest / k-nearest: exact, squared L2 in double, ties -> lower node index.  Small trees are scanned
+//     by the whole block (double2, coalesced); beyond 2048 nodes a uniform grid over the bounds (linked cell
+//     lists in HBM, ~4 nodes per cell at capacity) limits the scan to a square window of cells that doubles
+//     until the k-th candidate is provably closer than anything outside it; the k best of the window's
+//     candidates are picked by rank counting in LDS;
 //   * SteerTowards / SteerExactly / PathR2 (rrt_star.h:143-160, paths/path_r2.cpp) and the edge
 //     check (IsPathValid on the occupancy validator with theta = 0, or StateValidatorFree) are
 //     evaluated by the lanes, the reference's sequential choose-parent scan by thread 0.
-// Independent problems (different seeds / start-goal pairs) map to different workgroups.
+// Independent problems (different seeds / start-goal pairs) map to different workgroups (pp_rrt_run_batch).
 #include "pp_search_device.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <memory>
+#include <vector>
 
 using namespace ppd;
 
@@ -22,6 +27,8 @@ namespace {
 
 constexpr int RT = 512;          // threads per tree
 constexpr int kMaxNear = 16;     // k = max(1, (unsigned)log(N)) <= 16 up to N = e^17 = 2.4e7 nodes
+constexpr int kBruteMax = 2048;  // trees up to this size are scanned whole
+constexpr int kCandMax = 2048;   // candidates of one grid window held in LDS
 
 struct RrtArgs {
 	MapView m;
@@ -29,10 +36,15 @@ struct RrtArgs {
 	double lbx, lby, ubx, uby;
 	unsigned int maxIteration, maxNumberTreeNode;
 	double maxConnectionDistance, goalBias;
+	int star;
+	int capacity;      // allocated nodes per tree
+	int G;             // the spatial index has G x G cells over the bounds
+	double invHx, invHy, hMin; // cells per metre in x / y, smaller cell side
+};
+
+struct RrtProblem {
 	double initx, inity, goalx, goaly;
 	unsigned long long seed;
-	int star;
-	int capacity;      // allocated nodes
 };
 
 struct RrtOut {
@@ -91,8 +103,20 @@ __device__ __forceinline__ bool edge_valid(const RrtArgs& A, double x0, double y
 	return is_path_valid(A.m, sg, init, l, checks);
 }
 
-__global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, double2* __restrict__ pts, int32_t* __restrict__ parent, double* __restrict__ cost, RrtOut* __restrict__ out)
+__global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, const RrtProblem* __restrict__ problems, double2* __restrict__ ptsBase, int32_t* __restrict__ parentBase,
+	double* __restrict__ costBase, int32_t* __restrict__ cellHeadBase, int32_t* __restrict__ cellNextBase, RrtOut* __restrict__ outs)
 {
+	// one workgroup = one tree
+	const RrtProblem prob = problems[blockIdx.x];
+	double2* const pts = ptsBase + (size_t)blockIdx.x * A.capacity;
+	int32_t* const parent = parentBase + (size_t)blockIdx.x * A.capacity;
+	double* const cost = costBase + (size_t)blockIdx.x * A.capacity;
+	int32_t* const cellHead = cellHeadBase + (size_t)blockIdx.x * A.G * A.G; // -1 = empty (set by the host)
+	int32_t* const cellNext = cellNextBase + (size_t)blockIdx.x * A.capacity;
+	RrtOut* const out = outs + blockIdx.x;
+	__shared__ double candD[kCandMax];
+	__shared__ int candI[kCandMax];
+	__shared__ int s_cnt;
 	__shared__ unsigned long long mt[Mt64::N];
 	__shared__ double s_d[RT / 64];
 	__shared__ int s_i[RT / 64];
@@ -106,13 +130,22 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, double2* __restrict__ pts
 	const int tid = threadIdx.x;
 	// the RNG helpers are written for a 64-lane block: the first wave drives them
 	if (tid == 0)
-		Mt64::seed(mt, A.seed);
+		Mt64::seed(mt, prob.seed);
 	int mtIdx = Mt64::N;
 	if (tid == 0) {
-		pts[0] = make_double2(A.initx, A.inity); // Tree::CreateRootNode, tree.h:59-65
+		pts[0] = make_double2(prob.initx, prob.inity); // Tree::CreateRootNode, tree.h:59-65
 		parent[0] = -1;
 		cost[0] = 0.0;
 	}
+	auto cell_x = [&](double x) { return min(A.G - 1, max(0, (int)((x - A.lbx) * A.invHx))); };
+	auto cell_y = [&](double y) { return min(A.G - 1, max(0, (int)((y - A.lby) * A.invHy))); };
+	auto index_insert = [&](int node, double x, double y) { // thread 0
+		const int c = cell_x(x) * A.G + cell_y(y);
+		cellNext[node] = cellHead[c];
+		cellHead[c] = node;
+	};
+	if (tid == 0)
+		index_insert(0, prob.initx, prob.inity);
 	__syncthreads();
 	int n = 1;
 	long long iterations = 0, nKnn = 0, nEdge = 0;
@@ -153,6 +186,112 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, double2* __restrict__ pts
 		return lb + range * u;
 	};
 
+	// Exact k nearest of (px, py) by a scan of the whole tree -> nearD / nearI (ascending (d, index)).
+	auto brute_knn = [&](double px, double py, int k) {
+		// local top-k per thread (ascending), then k rounds of block arg-min over the heads
+		double ld[kMaxNear];
+		int li[kMaxNear];
+	#pragma unroll
+		for (int s = 0; s < kMaxNear; s++) {
+			ld[s] = __builtin_huge_val();
+			li[s] = 0x7FFFFFFF;
+		}
+		for (int i = tid; i < n; i += RT) {
+			const double2 p = pts[i];
+			const double dx = p.x - px, dy = p.y - py;
+			double cd = dx * dx + dy * dy;
+			int ci = i;
+			if (cand_before(cd, ci, ld[k - 1], li[k - 1])) {
+				bool ins = false;
+	#pragma unroll
+				for (int s = 0; s < kMaxNear; s++) {
+					if (s < k && (ins || cand_before(cd, ci, ld[s], li[s]))) {
+						const double td = ld[s];
+						const int ti = li[s];
+						ld[s] = cd;
+						li[s] = ci;
+						cd = td;
+						ci = ti;
+						ins = true;
+					}
+				}
+			}
+		}
+		int head = 0;
+		for (int r = 0; r < k; r++) {
+			double hd = __builtin_huge_val();
+			int hi = 0x7FFFFFFF;
+	#pragma unroll
+			for (int s = 0; s < kMaxNear; s++)
+				if (s == head) {
+					hd = ld[s];
+					hi = li[s];
+				}
+			const int mine = hi;
+			block_argmin(hd, hi, s_d, s_i);
+			if (tid == 0) {
+				nearD[r] = hd;
+				nearI[r] = hi;
+			}
+			if (mine == hi && hi != 0x7FFFFFFF)
+				head++;
+			__syncthreads();
+		}
+	};
+
+	// Exact k nearest of (px, py) through the cell lists -> nearD / nearI (ascending (d, index)); n > kBruteMax >= k.
+	// A window of (2r+1)^2 cells around the query's cell holds every node closer than r cell sides, so the search ends
+	// as soon as the k-th candidate is within that distance (or the window is the whole grid).
+	auto grid_knn = [&](double px, double py, int k) {
+		const int ci = cell_x(px), cj = cell_y(py);
+		for (int r = 1;; r *= 2) {
+			if (tid == 0)
+				s_cnt = 0;
+			__syncthreads();
+			const int i0 = max(0, ci - r), i1 = min(A.G - 1, ci + r), j0 = max(0, cj - r), j1 = min(A.G - 1, cj + r);
+			const int wj = j1 - j0 + 1, W = (i1 - i0 + 1) * wj;
+			for (int c = tid; c < W; c += RT) {
+				const int ii = i0 + c / wj, jj = j0 + c % wj;
+				for (int node = cellHead[ii * A.G + jj]; node >= 0; node = cellNext[node]) {
+					const double2 p = pts[node];
+					const double dx = p.x - px, dy = p.y - py;
+					const int slot = atomicAdd(&s_cnt, 1);
+					if (slot < kCandMax) {
+						candD[slot] = dx * dx + dy * dy;
+						candI[slot] = node;
+					}
+				}
+			}
+			__syncthreads();
+			const int M = s_cnt;
+			const bool whole = i0 == 0 && j0 == 0 && i1 == A.G - 1 && j1 == A.G - 1;
+			if (M > kCandMax) {
+				// more candidates than the LDS buffer (dense cluster): scan the whole tree with the block-wide top-k
+				__syncthreads();
+				brute_knn(px, py, k);
+				return;
+			}
+			// the k best by rank counting: candidate c is preceded by `rank` others in (d, index) order
+			for (int c = tid; c < M; c += RT) {
+				const double d = candD[c];
+				const int idx = candI[c];
+				int rank = 0;
+				for (int j = 0; j < M; j++)
+					rank += cand_before(candD[j], candI[j], d, idx) ? 1 : 0;
+				if (rank < k) {
+					nearD[rank] = d;
+					nearI[rank] = idx;
+				}
+			}
+			__syncthreads();
+			const double reach = (double)r * A.hMin * (1.0 - 1e-9); // nodes outside the window are farther than this
+			const bool done = whole || (M >= k && nearD[k - 1] <= reach * reach);
+			__syncthreads();
+			if (done)
+				return;
+		}
+	};
+
 	int count = -1;
 	while (true) {
 		count++;
@@ -166,25 +305,32 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, double2* __restrict__ pts
 		// ---- sample: goal with probability goalBias, else uniform in the bounds (x then y)
 		double rx, ry;
 		if (draw(0, 1) < A.goalBias) {
-			rx = A.goalx;
-			ry = A.goaly;
+			rx = prob.goalx;
+			ry = prob.goaly;
 		} else {
 			rx = draw(A.lbx, A.ubx); // StateSpaceR2::SampleUniform, state_space_r2.cpp:25-35
 			ry = draw(A.lby, A.uby);
 		}
 		// ---- nearest node (Tree::GetNearestNode)
-		double bd = __builtin_huge_val();
-		int bi = 0x7FFFFFFF;
-		for (int i = tid; i < n; i += RT) {
-			const double2 p = pts[i];
-			const double dx = p.x - rx, dy = p.y - ry;
-			const double d = dx * dx + dy * dy;
-			if (cand_before(d, i, bd, bi)) {
-				bd = d;
-				bi = i;
+		int bi;
+		if (n <= kBruteMax) {
+			double bd = __builtin_huge_val();
+			bi = 0x7FFFFFFF;
+			for (int i = tid; i < n; i += RT) {
+				const double2 p = pts[i];
+				const double dx = p.x - rx, dy = p.y - ry;
+				const double d = dx * dx + dy * dy;
+				if (cand_before(d, i, bd, bi)) {
+					bd = d;
+					bi = i;
+				}
 			}
+			block_argmin(bd, bi, s_d, s_i);
+		} else {
+			grid_knn(rx, ry, 1);
+			bi = nearI[0];
+			__syncthreads();
 		}
-		block_argmin(bd, bi, s_d, s_i);
 		nKnn++;
 		const int nearest = bi;
 		const double2 pn = pts[nearest];
@@ -217,14 +363,30 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, double2* __restrict__ pts
 			// ---- RRT: Extend(newState, nearestNode), rrt.h:80-82; an existing state returns its node (tree.h:127-129)
 			double ed = __builtin_huge_val();
 			int ei = 0x7FFFFFFF;
-			for (int i = tid; i < n; i += RT) {
-				const double2 p = pts[i];
-				if (p.x == nx && p.y == ny && i < ei) {
-					ed = 0.0;
-					ei = i;
+			if (n <= kBruteMax) {
+				for (int i = tid; i < n; i += RT) {
+					const double2 p = pts[i];
+					if (p.x == nx && p.y == ny && i < ei) {
+						ed = 0.0;
+						ei = i;
+					}
 				}
+				block_argmin(ed, ei, s_d, s_i);
+			} else {
+				// an identical state can only sit in the new state's own cell
+				if (tid == 0) {
+					int found = 0x7FFFFFFF;
+					for (int node = cellHead[cell_x(nx) * A.G + cell_y(ny)]; node >= 0; node = cellNext[node]) {
+						const double2 p = pts[node];
+						if (p.x == nx && p.y == ny && node < found)
+							found = node;
+					}
+					s_best = found;
+				}
+				__syncthreads();
+				ei = s_best;
+				__syncthreads();
 			}
-			block_argmin(ed, ei, s_d, s_i);
 			if (ei != 0x7FFFFFFF) {
 				newNode = ei;
 			} else {
@@ -233,11 +395,12 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, double2* __restrict__ pts
 					pts[n] = make_double2(nx, ny);
 					parent[n] = nearest;
 					cost[n] = 0.0;
+					index_insert(n, nx, ny);
 				}
 				n++;
 				__syncthreads();
 			}
-			const double gx = nx - A.goalx, gy = ny - A.goaly;
+			const double gx = nx - prob.goalx, gy = ny - prob.goaly;
 			if (sqrt(gx * gx + gy * gy) < 1) { // RRT::IsSolution, rrt.h:125-128
 				status = 0;
 				solution = newNode;
@@ -254,56 +417,11 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, double2* __restrict__ pts
 		if (k > n)
 			k = n;
 		nKnn++;
-		// local top-k per thread (ascending), then k rounds of block arg-min over the heads
-		double ld[kMaxNear];
-		int li[kMaxNear];
+		if (n <= kBruteMax)
+			brute_knn(nx, ny, k);
+		else
+			grid_knn(nx, ny, k);
 		const int kk = k;
-#pragma unroll
-		for (int s = 0; s < kMaxNear; s++) {
-			ld[s] = __builtin_huge_val();
-			li[s] = 0x7FFFFFFF;
-		}
-		for (int i = tid; i < n; i += RT) {
-			const double2 p = pts[i];
-			const double dx = p.x - nx, dy = p.y - ny;
-			double cd = dx * dx + dy * dy;
-			int ci = i;
-			if (cand_before(cd, ci, ld[kk - 1], li[kk - 1])) {
-				bool ins = false;
-#pragma unroll
-				for (int s = 0; s < kMaxNear; s++) {
-					if (s < kk && (ins || cand_before(cd, ci, ld[s], li[s]))) {
-						const double td = ld[s];
-						const int ti = li[s];
-						ld[s] = cd;
-						li[s] = ci;
-						cd = td;
-						ci = ti;
-						ins = true;
-					}
-				}
-			}
-		}
-		int head = 0;
-		for (int r = 0; r < kk; r++) {
-			double hd = __builtin_huge_val();
-			int hi = 0x7FFFFFFF;
-#pragma unroll
-			for (int s = 0; s < kMaxNear; s++)
-				if (s == head) {
-					hd = ld[s];
-					hi = li[s];
-				}
-			const int mine = hi;
-			block_argmin(hd, hi, s_d, s_i);
-			if (tid == 0) {
-				nearD[r] = hd;
-				nearI[r] = hi;
-			}
-			if (mine == hi && hi != 0x7FFFFFFF)
-				head++;
-			__syncthreads();
-		}
 		// ---- choose parent: lanes evaluate SteerExactly + IsPathValid of every candidate
 		if (tid < kk) {
 			const int node = nearI[tid];
@@ -346,6 +464,7 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, double2* __restrict__ pts
 			if (tid == 0) {
 				pts[n] = make_double2(nx, ny);
 				parent[n] = bestParent >= 0 ? bestParent : nn0; // null parent -> nearest node (tree.h:131)
+				index_insert(n, nx, ny);
 			}
 			n++;
 			if (bestParent < 0)
@@ -354,7 +473,7 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, double2* __restrict__ pts
 		if (tid == 0)
 			cost[newNode] = bestCost;
 		__syncthreads();
-		if (nx == A.goalx && ny == A.goaly) { // RRTStar::IsSolution: exact equality, rrt_star.h:136-139
+		if (nx == prob.goalx && ny == prob.goaly) { // RRTStar::IsSolution: exact equality, rrt_star.h:136-139
 			status = 0;
 			solution = newNode;
 			break;
@@ -382,16 +501,22 @@ struct pp_rrt {
 
 extern "C" {
 
-int pp_rrt_run(pp_ctx* ctx, pp_map* map, const double lower[2], const double upper[2], const double params[4], const double init[2], const double goal[2],
-	uint64_t seed, int32_t star, pp_rrt** out, pp_rrt_result* result)
+int pp_rrt_run_batch(pp_ctx* ctx, pp_map* map, const double lower[2], const double upper[2], const double params[4], int32_t n_problems,
+	const double* inits_xy, const double* goals_xy, const uint64_t* seeds, int32_t star, pp_rrt** outs, pp_rrt_result* results)
 {
 	using pph::set_error;
-	if (!ctx || !lower || !upper || !params || !init || !goal || !out || !result) {
+	if (!ctx || !lower || !upper || !params || n_problems < 0 || (n_problems > 0 && (!inits_xy || !goals_xy || !seeds || !outs || !results))) {
 		set_error("null argument");
 		return PP_ERR_INVALID;
 	}
+	if (n_problems == 0)
+		return PP_OK;
 	if (map && !map->dist) {
 		set_error("distance grid not uploaded (pp_map_upload_dist2)");
+		return PP_ERR_INVALID;
+	}
+	if (!(upper[0] > lower[0]) || !(upper[1] > lower[1])) {
+		set_error("empty bounds");
 		return PP_ERR_INVALID;
 	}
 	PP_HIP_TRY(hipSetDevice(ctx->device));
@@ -408,76 +533,116 @@ int pp_rrt_run(pp_ctx* ctx, pp_map* map, const double lower[2], const double upp
 	A.maxNumberTreeNode = (unsigned int)params[1];
 	A.maxConnectionDistance = params[2];
 	A.goalBias = params[3];
-	A.initx = init[0];
-	A.inity = init[1];
-	A.goalx = goal[0];
-	A.goaly = goal[1];
-	A.seed = seed;
 	A.star = star;
 	// the loop stops once size > maxNumberTreeNode or after maxIteration + 1 iterations
 	const unsigned long long cap = std::min<unsigned long long>((unsigned long long)A.maxNumberTreeNode + 2ull, (unsigned long long)A.maxIteration + 3ull);
-	if (cap > (1ull << 28)) {
-		set_error("tree too large");
+	if (cap > (1ull << 28) || cap * (unsigned long long)n_problems > (1ull << 32)) {
+		set_error("tree(s) too large");
 		return PP_ERR_INVALID;
 	}
 	A.capacity = (int)cap;
+	// spatial index: about four nodes per cell when the tree is full
+	int G = (int)std::ceil(std::sqrt((double)cap / 4.0));
+	A.G = G < 1 ? 1 : (G > 2048 ? 2048 : G);
+	A.invHx = A.G / (upper[0] - lower[0]);
+	A.invHy = A.G / (upper[1] - lower[1]);
+	A.hMin = std::min((upper[0] - lower[0]) / A.G, (upper[1] - lower[1]) / A.G);
+	const size_t np = (size_t)n_problems;
+	std::vector<RrtProblem> probs(np);
+	for (size_t i = 0; i < np; i++) {
+		probs[i].initx = inits_xy[2 * i];
+		probs[i].inity = inits_xy[2 * i + 1];
+		probs[i].goalx = goals_xy[2 * i];
+		probs[i].goaly = goals_xy[2 * i + 1];
+		probs[i].seed = seeds[i];
+	}
+	RrtProblem* dprob = nullptr;
 	double2* pts = nullptr;
-	int32_t* parent = nullptr;
+	int32_t *parent = nullptr, *cellHead = nullptr, *cellNext = nullptr;
 	double* cost = nullptr;
 	RrtOut* dout = nullptr;
-	hipError_t e = hipMalloc((void**)&pts, cap * sizeof(double2));
+	const size_t cells = (size_t)A.G * A.G;
+	hipError_t e = hipMalloc((void**)&pts, np * cap * sizeof(double2));
 	if (e == hipSuccess)
-		e = hipMalloc((void**)&parent, cap * 4);
+		e = hipMalloc((void**)&parent, np * cap * 4);
 	if (e == hipSuccess)
-		e = hipMalloc((void**)&cost, cap * 8);
+		e = hipMalloc((void**)&cost, np * cap * 8);
 	if (e == hipSuccess)
-		e = hipMalloc((void**)&dout, sizeof(RrtOut));
-	RrtOut ho;
-	std::memset(&ho, 0, sizeof(ho));
-	auto r = std::make_unique<pp_rrt>();
+		e = hipMalloc((void**)&cellNext, np * cap * 4);
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&cellHead, np * cells * 4);
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&dout, np * sizeof(RrtOut));
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&dprob, np * sizeof(RrtProblem));
+	std::vector<RrtOut> ho(np);
+	std::vector<std::unique_ptr<pp_rrt>> rs(np);
+	if (e == hipSuccess)
+		e = hipMemsetAsync(cellHead, 0xFF, np * cells * 4, ctx->stream); // -1 = empty cell
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(dprob, probs.data(), np * sizeof(RrtProblem), hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_rrt, dim3(1), dim3(RT), 0, ctx->stream, A, pts, parent, cost, dout);
+		hipLaunchKernelGGL(k_rrt, dim3(n_problems), dim3(RT), 0, ctx->stream, A, dprob, pts, parent, cost, cellHead, cellNext, dout);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess)
-		e = hipMemcpyAsync(&ho, dout, sizeof(RrtOut), hipMemcpyDeviceToHost, ctx->stream);
+		e = hipMemcpyAsync(ho.data(), dout, np * sizeof(RrtOut), hipMemcpyDeviceToHost, ctx->stream);
 	if (e == hipSuccess)
 		e = hipStreamSynchronize(ctx->stream);
-	if (e == hipSuccess) {
-		const int n = ho.nNodes;
+	for (size_t i = 0; i < np && e == hipSuccess; i++) {
+		rs[i] = std::make_unique<pp_rrt>();
+		pp_rrt* r = rs[i].get();
+		const int n = ho[i].nNodes;
 		r->nodes.resize((size_t)n * 2);
 		r->parents.resize(n);
 		r->costs.resize(n);
-		e = hipMemcpy(r->nodes.data(), pts, (size_t)n * 16, hipMemcpyDeviceToHost);
+		e = hipMemcpy(r->nodes.data(), pts + i * cap, (size_t)n * 16, hipMemcpyDeviceToHost);
 		if (e == hipSuccess)
-			e = hipMemcpy(r->parents.data(), parent, (size_t)n * 4, hipMemcpyDeviceToHost);
+			e = hipMemcpy(r->parents.data(), parent + i * cap, (size_t)n * 4, hipMemcpyDeviceToHost);
 		if (e == hipSuccess)
-			e = hipMemcpy(r->costs.data(), cost, (size_t)n * 8, hipMemcpyDeviceToHost);
+			e = hipMemcpy(r->costs.data(), cost + i * cap, (size_t)n * 8, hipMemcpyDeviceToHost);
 	}
 	(void)hipFree(pts);
 	(void)hipFree(parent);
 	(void)hipFree(cost);
+	(void)hipFree(cellNext);
+	(void)hipFree(cellHead);
 	(void)hipFree(dout);
+	(void)hipFree(dprob);
 	if (e != hipSuccess)
-		return pph::hip_fail(e, "pp_rrt_run");
-	// GetPath, rrt.h:97-115: states from the root to the solution node
-	if (ho.solution >= 0) {
-		std::vector<int> chain;
-		for (int k = ho.solution; k >= 0; k = r->parents[k])
-			chain.push_back(k);
-		for (size_t i = chain.size(); i-- > 0;) {
-			r->path.push_back(r->nodes[2 * chain[i]]);
-			r->path.push_back(r->nodes[2 * chain[i] + 1]);
+		return pph::hip_fail(e, "pp_rrt_run_batch");
+	for (size_t i = 0; i < np; i++) {
+		pp_rrt* r = rs[i].get();
+		// GetPath, rrt.h:97-115: states from the root to the solution node
+		if (ho[i].solution >= 0) {
+			std::vector<int> chain;
+			for (int k = ho[i].solution; k >= 0; k = r->parents[k])
+				chain.push_back(k);
+			for (size_t j = chain.size(); j-- > 0;) {
+				r->path.push_back(r->nodes[2 * chain[j]]);
+				r->path.push_back(r->nodes[2 * chain[j] + 1]);
+			}
 		}
+		results[i].status = ho[i].status;
+		results[i].n_nodes = ho[i].nNodes;
+		results[i].n_path = (int32_t)(r->path.size() / 2);
+		results[i].iterations = ho[i].iterations;
+		results[i].n_knn_queries = ho[i].nKnn;
+		results[i].n_edge_checks = ho[i].nEdge;
 	}
-	result->status = ho.status;
-	result->n_nodes = ho.nNodes;
-	result->n_path = (int32_t)(r->path.size() / 2);
-	result->iterations = ho.iterations;
-	result->n_knn_queries = ho.nKnn;
-	result->n_edge_checks = ho.nEdge;
-	*out = r.release();
+	for (size_t i = 0; i < np; i++)
+		outs[i] = rs[i].release();
 	return PP_OK;
+}
+
+int pp_rrt_run(pp_ctx* ctx, pp_map* map, const double lower[2], const double upper[2], const double params[4], const double init[2], const double goal[2],
+	uint64_t seed, int32_t star, pp_rrt** out, pp_rrt_result* result)
+{
+	if (!init || !goal || !out || !result) {
+		pph::set_error("null argument");
+		return PP_ERR_INVALID;
+	}
+	return pp_rrt_run_batch(ctx, map, lower, upper, params, 1, init, goal, &seed, star, out, result);
 }
 
 int pp_rrt_get(pp_rrt* r, double* nodes_xy, int32_t* parents, double* costs, double* path_xy)

@@ -509,6 +509,33 @@ class _RRTBase:
     def get_path(self):
         return self.result["path"] if self.result is not None else np.empty((0, 2))
 
+    def search_batch(self, inits, goals, seeds):
+        """n independent problems (own start, goal, seed), one workgroup each, run together on the GPU.
+        Returns one result dict per problem (same fields as `self.result`)."""
+        inits = np.ascontiguousarray(inits, dtype=np.float64).reshape(-1, 2)
+        goals = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 2)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        n = len(inits)
+        assert goals.shape == inits.shape and seeds.shape == (n,)
+        params = np.array([self.max_iteration, self.max_number_tree_node, self.max_connection_distance, self.goal_bias], dtype=np.float64)
+        hs = (C.c_void_p * n)()
+        res = (_lib.RrtResult * n)()
+        mh = self.validator.map.h if self.validator is not None else None
+        check(self.lib.pp_rrt_run_batch(self.ctx.h, mh, ptr(self.lower), ptr(self.upper), ptr(params), n, ptr(inits), ptr(goals), ptr(seeds), self._star,
+                                        C.cast(hs, C.POINTER(C.c_void_p)), res))
+        out = []
+        for i in range(n):
+            nodes = np.empty((res[i].n_nodes, 2))
+            parents = np.empty(res[i].n_nodes, dtype=np.int32)
+            costs = np.empty(res[i].n_nodes)
+            path = np.empty((res[i].n_path, 2))
+            h = C.c_void_p(hs[i])
+            check(self.lib.pp_rrt_get(h, ptr(nodes), ptr(parents), ptr(costs), ptr(path)))
+            self.lib.pp_rrt_destroy(h)
+            out.append(dict(status=res[i].status, nodes=nodes, parents=parents, costs=costs, path=path, iterations=res[i].iterations,
+                            n_knn=res[i].n_knn_queries, n_edge_checks=res[i].n_edge_checks))
+        return out
+
 
 class RRT(_RRTBase):
     _star = 0

@@ -74,3 +74,23 @@ def test_rrt_star_on_occupancy_map():
         want = O.rrt(w, lb, ub, [-11.0, -11.0], [11.0, 11.0], seed, star=star, max_iteration=6000, max_nodes=6000, max_connection=0.512, goal_bias=0.05)
         same_tree(r.result, want)
         assert len(want["nodes"]) > 100
+
+
+def test_rrt_batch_equals_single_runs_and_oracle():
+    """pp_rrt_run_batch: independent problems, one workgroup each; every tree equals the oracle's (and trees beyond
+    2048 nodes go through the cell-list index: exact nearest / k-nearest with ties to the lower index)."""
+    import pathplanning_amd as pa
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    lb, ub = w.lb[:2], w.ub[:2]
+    inits = np.array([[-11.0, -11.0], [10.0, -9.0], [0.5, 11.5], [-11.0, 11.0]])
+    goals = np.array([[11.0, 11.0], [-10.0, 9.0], [3.0, -11.0], [100.0, 100.0]])  # last goal outside: runs every iteration
+    seeds = np.array([5, 6, 7, 8], dtype=np.uint64)
+    for star in (True, False):
+        cls = pa.RRTStar if star else pa.RRT
+        r = cls(ctx, lb, ub, validator=val, max_iteration=5000, max_number_tree_node=5000, max_connection_distance=0.512, goal_bias=0.05)
+        got = r.search_batch(inits, goals, seeds)
+        assert len(got) == 4
+        for i in range(4):
+            want = O.rrt(w, lb, ub, inits[i], goals[i], int(seeds[i]), star=star, max_iteration=5000, max_nodes=5000, max_connection=0.512, goal_bias=0.05)
+            same_tree(got[i], want)
+        assert len(got[3]["nodes"]) > 2048
