@@ -15,8 +15,9 @@ from pathplanning_amd import synthetic  # noqa: E402
 from pathplanning_amd._lib import check, ptr  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 768
+CELLS = int(sys.argv[3]) if len(sys.argv) > 3 else 1024  # map side in cells
 ctx = pa.Context(0)
-m = synthetic.make_map(1024, 24, seed=1)
+m = synthetic.make_map(CELLS, 24 * (CELLS // 1024) ** 2 if CELLS >= 1024 else 12, seed=1)
 ms, val = synthetic.upload(ctx, m)
 goals = synthetic.sample_valid_poses(val, m, G, seed=2000)[:, :2].copy()
 cnt = np.zeros((G, 16), dtype=np.uint64)
@@ -37,7 +38,7 @@ print("offer: store-wait %.0f  loads %.0f  count+barrier %.0f  (whole offer to e
 G2 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 if G2:
     goals2 = synthetic.sample_valid_poses(val, m, G2, seed=2001)[:, :2].copy()
-    out = torch.empty((G2, 1024 * 1024), dtype=torch.float32, device="cuda")
+    out = torch.empty((G2, CELLS * CELLS), dtype=torch.float32, device="cuda")
     for it in range(3):
         ctx.timer_start()
         check(ctx.lib.pp_obstacle_heuristic_dev(ms.h, G2, ptr(np.ascontiguousarray(goals2)), out.data_ptr()))
