@@ -145,9 +145,10 @@ int pp_nonholo_build(pp_ctx* ctx, const double lower[3], const double upper[3], 
  * no relaxation, LIFO ties).  goal_xy: world positions. */
 int pp_obstacle_heuristic_dev(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev);
 int pp_obstacle_heuristic(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_host);
-/* Diagnostics: stamped build of the wavefront kernel; per goal 16 words {init, min, partition, sort, offer, push,
- * tail cycles, rounds, sum of window sizes, sum of padded sort sizes, fallback rounds, push cycles of fallback rounds,
- * offer sub-phases: store wait, neighbourhood loads, candidate count, whole offer up to the end of insertion}. */
+/* Diagnostics: stamped build of the wavefront kernel; per goal 20 words {init, min, partition, sort, offer, push,
+ * tail cycles, rounds, sum of window sizes, rounds with the open list in HBM, fallback rounds, push cycles of fallback rounds,
+ * offer sub-phases: store wait, neighbourhood loads, candidate count, whole offer up to the end of insertion,
+ * push sub-phases (cumulative from the start of push): look-up, slot scan, stores; one pad word}. */
 int pp_obstacle_heuristic_profile(pp_map* map, int32_t n_goals, const double* goal_xy_host, uint64_t* counters_host);
 /* bytes of scratch pp_obstacle_heuristic_dev keeps per concurrently running goal */
 int64_t pp_obstacle_heuristic_workspace_bytes(pp_map* map);

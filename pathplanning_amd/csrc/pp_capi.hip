@@ -687,11 +687,11 @@ int pp_obstacle_heuristic_profile(pp_map* map, int32_t n_goals, const double* go
 	PP_HIP_TRY(dc.alloc((size_t)n_goals * 4));
 	PP_HIP_TRY(derr.alloc(8));
 	PP_HIP_TRY(dcost.alloc((size_t)n_goals * map->cells() * 4));
-	PP_HIP_TRY(dprof.alloc((size_t)n_goals * 16 * 8));
+	PP_HIP_TRY(dprof.alloc((size_t)n_goals * 20 * 8));
 	PP_HIP_TRY(hipMemsetAsync(derr.p, 0, 8, s));
 	PP_HIP_TRY(hipMemcpyAsync(dc.p, cells.data(), (size_t)n_goals * 4, hipMemcpyHostToDevice, s));
 	PP_HIP_TRY(launch_wavefront(s, map->view(), n_goals, dc.as<int32_t>(), dcost.as<float>(), ws.p, wsb, nSlots, derr.as<int32_t>(), dprof.as<unsigned long long>()));
-	PP_HIP_TRY(hipMemcpyAsync(counters_host, dprof.p, (size_t)n_goals * 16 * 8, hipMemcpyDeviceToHost, s));
+	PP_HIP_TRY(hipMemcpyAsync(counters_host, dprof.p, (size_t)n_goals * 20 * 8, hipMemcpyDeviceToHost, s));
 	PP_HIP_TRY(hipStreamSynchronize(s));
 	return PP_OK;
 }

@@ -274,34 +274,49 @@ struct Row3 {
 };
 /// States of the 3 x 3 block around padded cell (pr, pcc) from the tiled grid.  A tile row is 8 aligned bytes, so each
 /// of the three rows is ONE 8-byte load; only cells in the first / last column of a tile (1 in 4) also need the
-/// adjacent tile's edge byte.
-__device__ __forceinline__ void load_state_nbhd(const uint8_t* __restrict__ state, int tpr, int pr, int pcc, Row3& up, Row3& mid, Row3& dn)
-{
-	const int x = pcc & 7;
-	uint32_t base[3];
+/// adjacent tile's edge byte.  Issue and use are separate so that the loads can fly under other work.
+struct NbhdRaw {
 	unsigned long long w[3];
+	uint32_t side[3];
+	int x;
+};
+__device__ __forceinline__ NbhdRaw nbhd_issue(const uint8_t* __restrict__ state, int tpr, int pr, int pcc)
+{
+	NbhdRaw r;
+	r.x = pcc & 7;
+	uint32_t base[3];
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
 		const int rr = pr - 1 + k;
 		base[k] = ((uint32_t)((rr >> 3) * tpr + (pcc >> 3)) << 6) | (uint32_t)((rr & 7) << 3);
-		w[k] = *reinterpret_cast<const unsigned long long*>(state + base[k]);
+		r.w[k] = *reinterpret_cast<const unsigned long long*>(state + base[k]);
+		r.side[k] = 0;
 	}
-	uint32_t side[3] = { 0, 0, 0 };
-	if (x == 0 || x == 7) {
-		const int off = x ? 64 : -57; // same row of the next tile (its byte 0) / of the previous tile (its byte 7)
+	if (r.x == 0 || r.x == 7) {
+		const int off = r.x ? 64 : -57; // same row of the next tile (its byte 0) / of the previous tile (its byte 7)
 #pragma unroll
 		for (int k = 0; k < 3; k++)
-			side[k] = state[(int)base[k] + off];
+			r.side[k] = state[(int)base[k] + off];
 	}
+	return r;
+}
+__device__ __forceinline__ void nbhd_finish(const NbhdRaw& r, Row3& up, Row3& mid, Row3& dn)
+{
+	const int x = r.x;
 	Row3* out[3] = { &up, &mid, &dn };
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
-		const uint32_t lo = (uint32_t)(w[k] >> ((x ? x - 1 : 0) * 8)) & 0xFFu;
-		const uint32_t hi = (uint32_t)(w[k] >> ((x < 7 ? x + 1 : 7) * 8)) & 0xFFu;
-		out[k]->a = x == 0 ? side[k] : lo;
-		out[k]->b = (uint32_t)(w[k] >> (x * 8)) & 0xFFu;
-		out[k]->c = x == 7 ? side[k] : hi;
+		const uint32_t lo = (uint32_t)(r.w[k] >> ((x ? x - 1 : 0) * 8)) & 0xFFu;
+		const uint32_t hi = (uint32_t)(r.w[k] >> ((x < 7 ? x + 1 : 7) * 8)) & 0xFFu;
+		out[k]->a = x == 0 ? r.side[k] : lo;
+		out[k]->b = (uint32_t)(r.w[k] >> (x * 8)) & 0xFFu;
+		out[k]->c = x == 7 ? r.side[k] : hi;
 	}
+}
+__device__ __forceinline__ void load_state_nbhd(const uint8_t* __restrict__ state, int tpr, int pr, int pcc, Row3& up, Row3& mid, Row3& dn)
+{
+	const NbhdRaw r = nbhd_issue(state, tpr, pr, pcc);
+	nbhd_finish(r, up, mid, dn);
 }
 /// three consecutive 32-bit words (fallback path: rank words)
 __device__ __forceinline__ Row3 load_row3(const uint32_t* p)
@@ -342,7 +357,7 @@ __device__ __forceinline__ uint32_t candidate_mask(const Row3& up, const Row3& m
 }
 
 // kProfile: diagnostic build -- per goal {init, min, partition, sort, offer, push, tail} shader-clock sums + rounds, sum(w), sum(P)
-enum { WP_INIT = 0, WP_MIN, WP_PART, WP_SORT, WP_OFFER, WP_PUSH, WP_TAIL, WP_ROUNDS, WP_SUMW, WP_SUMP, WP_FBROUNDS, WP_FBCYC, WP_O_WAIT, WP_O_LOAD, WP_O_COUNT, WP_O_INSERT, WP_COUNT };
+enum { WP_INIT = 0, WP_MIN, WP_PART, WP_SORT, WP_OFFER, WP_PUSH, WP_TAIL, WP_ROUNDS, WP_SUMW, WP_SUMP, WP_FBROUNDS, WP_FBCYC, WP_O_WAIT, WP_O_LOAD, WP_O_COUNT, WP_O_INSERT, WP_P_LOOKUP, WP_P_SCAN, WP_P_STORE, WP_P_PAD, WP_COUNT };
 
 constexpr int WF_LIST = 4096; // open-list entries kept in LDS (32 KiB); beyond that the list lives in HBM
 constexpr int WF_NB = 2048;   // buckets of the rank sort
@@ -462,6 +477,98 @@ __device__ __forceinline__ void rank_sort(uint64_t* skey, uint32_t* hist, uint32
 	lds_barrier();
 }
 
+/// rank_sort for windows of at most 4 * WF_T cells that ALSO fetches every window cell's 3 x 3 state block: the loads
+/// are issued before the first sorting step and consumed after the last one, so the memory round trip (~10 k cycles,
+/// the largest single item of a round) runs under the seven LDS steps of the sort.  smask[rank] receives the
+/// candidate mask of the cell that ends up at `rank`.  Starts with a full barrier: the state bytes stored by the
+/// previous round must be visible to the loads.
+__device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, uint32_t* wsum, uint8_t* smask, uint32_t w, uint32_t range, int shiftD,
+	const uint8_t* __restrict__ state, int tpr, int cb, uint32_t cellMask)
+{
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int bitsRange = range > 1u ? 32 - __clz((int)(range - 1u)) : 0;
+	const int shift = bitsRange > 11 ? bitsRange - 11 : 0; // (cost - L) >> shift < WF_NB
+	uint64_t k[4];
+	uint32_t meta[4];
+	NbhdRaw raw[4];
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		k[u] = i < w ? skey[SK((int)i)] : ~0ull;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		if (i < w) {
+			const uint32_t cell = unpack_cell((uint32_t)k[u] & cellMask, cb);
+			raw[u] = nbhd_issue(state, tpr, (int)(cell >> 16), (int)(cell & 0xFFFFu));
+		}
+	}
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		if (i < w) {
+			const uint32_t bkt = (uint32_t)(k[u] >> shiftD) >> shift;
+			const uint32_t arr = atomicAdd(&hist[bkt], 1u);
+			meta[u] = bkt | (arr << 11);
+		}
+	}
+	lds_barrier();
+	uint4 h = reinterpret_cast<uint4*>(hist)[tid];
+	const uint32_t s0 = h.x, s1 = s0 + h.y, s2 = s1 + h.z, s3 = s2 + h.w;
+	const uint32_t incl = wave_incl_add(s3);
+	if (lane == 63)
+		wsum[wave] = incl;
+	lds_barrier();
+	uint32_t base = incl - s3;
+#pragma unroll
+	for (int v = 0; v < WF_W; v++)
+		base += v < wave ? wsum[v] : 0u;
+	reinterpret_cast<uint4*>(hist)[tid] = make_uint4(base, base + s0, base + s1, base + s2);
+	lds_barrier();
+	bool multi = false;
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		if (i < w) {
+			const uint32_t bkt = meta[u] & (WF_NB - 1), arr = meta[u] >> 11;
+			const uint32_t st = hist[bkt], en = bkt + 1 < (uint32_t)WF_NB ? hist[bkt + 1] : w;
+			skey[SK((int)(st + arr))] = k[u];
+			meta[u] = st | ((en - st) << 12);
+			multi = multi || en - st > 1u;
+		}
+	}
+	lds_barrier();
+	reinterpret_cast<uint4*>(hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		if (i < w) {
+			const uint32_t st = meta[u] & 0xFFFu, size = meta[u] >> 12;
+			uint32_t rank = st;
+			if (size > 1u)
+				for (uint32_t p = st; p < st + size; p++)
+					rank += skey[SK((int)p)] < k[u];
+			meta[u] = rank;
+		}
+	}
+	lds_barrier();
+#pragma unroll
+	for (int u = 0; u < 4; u++) {
+		const uint32_t i = (uint32_t)(tid + u * WF_T);
+		if (i < w) {
+			if (multi) // a lane whose buckets are all singletons already sits at its rank
+				skey[SK((int)meta[u])] = k[u];
+			Row3 up, mid, dn;
+			nbhd_finish(raw[u], up, mid, dn); // first use of the loaded words: the wait for them sits here
+			smask[meta[u]] = (uint8_t)candidate_mask(up, mid, dn);
+		}
+	}
+	lds_barrier();
+}
+
 #ifndef PP_WF_WAVES_PER_SIMD
 #define PP_WF_WAVES_PER_SIMD 4 // 2 workgroups of 8 waves per CU: <= 128 VGPRs
 #endif
@@ -481,6 +588,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 	__shared__ uint64_t skey[kSkewed(WF_LCAP)]; // window keys (skewed layout), then (as two uint32 arrays) the claim hash table
 	__shared__ uint64_t lent[WF_LIST];           // open list in LDS, in push order: cost bits << 32 | padded cell
 	__shared__ __attribute__((aligned(16))) uint32_t hist[WF_NB];
+	__shared__ uint8_t smask[4 * WF_T];           // candidate mask per window rank (rank_sort_masks)
 	__shared__ uint32_t s_wcnt[64];              // ordered compaction: counts per (chunk row u, wave)
 	__shared__ uint64_t s_wtot[WF_W];
 	__shared__ uint32_t s_wsum[WF_W];
@@ -705,8 +813,11 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				overflow = true;
 				break;
 			}
+			const bool prefetched = fast && w > 1 && w <= 4u * WF_T; // masks come out of the sort
 			if (fast) {
-				if (w > 1)
+				if (prefetched)
+					rank_sort_masks(skey, hist, s_wsum, smask, w, hiBits - lBits, shiftD, state, tpr, cb, cellMask);
+				else if (w > 1)
 					rank_sort(skey, hist, s_wsum, w, hiBits - lBits, shiftD);
 			} else {
 				const uint32_t P = w <= 1 ? 2 : (1u << (32 - __clz((int)(w - 1))));
@@ -720,7 +831,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			if (kProfile) {
 				ph[WP_ROUNDS]++;
 				ph[WP_SUMW] += w;
-				ph[WP_SUMP] += w;
+				ph[WP_SUMP] += inLds ? 0 : 1; // rounds whose open list lives in HBM
 			}
 			uint32_t newMin = 0xFFFFFFFFu;
 			uint32_t newCount = 0;
@@ -750,26 +861,41 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						myCost[q] = lBits + (uint32_t)(k >> shiftD);
 					}
 				}
-				__syncthreads(); // the state bytes stored by the previous round are visible from here on
 				unsigned long long ts_ = 0;
-				if (kProfile) {
-					ts_ = clock64();
-					ph[WP_O_WAIT] += ts_ - tl;
-				}
-				Row3 up[4], mid[4], dn[4];
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					const uint32_t i = tid + q * WF_T;
-					if (i < w)
-						load_state_nbhd(state, tpr, (int)(myCell[q] >> 16), (int)(myCell[q] & 0xFFFFu), up[q], mid[q], dn[q]);
-				}
 				uint32_t cnt = 0;
+				if (prefetched) {
+					if (kProfile) {
+						ts_ = clock64();
+						ph[WP_O_WAIT] += ts_ - tl;
+					}
 #pragma unroll
-				for (int q = 0; q < 4; q++) {
-					const uint32_t i = tid + q * WF_T;
-					if (i < w) {
-						myMask[q] = candidate_mask(up[q], mid[q], dn[q]);
-						cnt += __popc(myMask[q]);
+					for (int q = 0; q < 4; q++) {
+						const uint32_t i = tid + q * WF_T;
+						if (i < w) {
+							myMask[q] = smask[i];
+							cnt += __popc(myMask[q]);
+						}
+					}
+				} else {
+					__syncthreads(); // the state bytes stored by the previous round are visible from here on
+					if (kProfile) {
+						ts_ = clock64();
+						ph[WP_O_WAIT] += ts_ - tl;
+					}
+					Row3 up[4], mid[4], dn[4];
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const uint32_t i = tid + q * WF_T;
+						if (i < w)
+							load_state_nbhd(state, tpr, (int)(myCell[q] >> 16), (int)(myCell[q] & 0xFFFFu), up[q], mid[q], dn[q]);
+					}
+#pragma unroll
+					for (int q = 0; q < 4; q++) {
+						const uint32_t i = tid + q * WF_T;
+						if (i < w) {
+							myMask[q] = candidate_mask(up[q], mid[q], dn[q]);
+							cnt += __popc(myMask[q]);
+						}
 					}
 				}
 				if (kProfile) {
@@ -836,6 +962,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					if (hkey[h] == key)
 						winBits |= 1u << bit;
 				}
+				if (kProfile)
+					ph[WP_P_LOOKUP] += clock64() - tl;
 				// per-q counts packed in 16-bit fields (a field never exceeds 4096)
 				const uint32_t c01 = (uint32_t)__popc(winBits & 0xFFu) | ((uint32_t)__popc(winBits & 0xFF00u) << 16);
 				const uint32_t c23 = (uint32_t)__popc(winBits & 0xFF0000u) | ((uint32_t)__popc(winBits & 0xFF000000u) << 16);
@@ -859,22 +987,26 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 					run += (uint32_t)((all >> (16 * q)) & 0xFFFFu);
 				}
 				newCount = run;
+				if (kProfile)
+					ph[WP_P_SCAN] += clock64() - tl;
 				pushLds = inLds && b + newCount <= (uint32_t)WF_LIST;
 				if (inLds && !pushLds)
 					spill_list();
+				// each lane walks its own wins (a handful per row q), lowest bit first = ascending j
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
-					if (!((winBits >> (q * 8)) & 0xFFu))
-						continue;
-					const float ci = __uint_as_float(myCost[q]);
 					uint32_t slot = qBase[q];
+					uint32_t rem = (winBits >> (q * 8)) & 0xFFu;
 #pragma unroll
-					for (int j = 0; j < 8; j++) {
-						if (!(winBits & (1u << (q * 8 + j))))
-							continue;
-						const uint32_t ncell = myCell[q] + (uint32_t)nbOff[j];
-						const float transitionCost = (kDr[j] == 0 || kDc[j] == 0) ? 1.0f : kDiag;
-						const float pathCost = transitionCost + ci; // heuristics.cpp:135
+					for (int it = 0; it < 8; it++) { // at most 8 wins per row; the trip count is the lane's own
+						if (!rem)
+							break;
+						const int j = __ffs((int)rem) - 1;
+						rem &= rem - 1u;
+						const int dr = dir_dr(j), dc = dir_dc(j);
+						const uint32_t ncell = myCell[q] + (uint32_t)(dr * 65536 + dc);
+						const float transitionCost = (dr == 0 || dc == 0) ? 1.0f : kDiag;
+						const float pathCost = transitionCost + __uint_as_float(myCost[q]); // heuristics.cpp:135
 						const uint32_t pb = __float_as_uint(pathCost);
 						const int nr = (int)(ncell >> 16), nc = (int)(ncell & 0xFFFFu);
 						state[st_addr(tpr, nr, nc)] = (uint8_t)ST_SEEN;
@@ -989,6 +1121,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				}
 				newCount = runBase - b;
 			}
+			if (kProfile && hashed)
+				ph[WP_P_STORE] += clock64() - tl;
 			newMin = wave_min(newMin);
 			if (lane == 0 && newMin != 0xFFFFFFFFu)
 				atomicMin(&s_minNext[par], newMin);

@@ -20,7 +20,7 @@ ctx = pa.Context(0)
 m = synthetic.make_map(CELLS, 24 * (CELLS // 1024) ** 2 if CELLS >= 1024 else 12, seed=1)
 ms, val = synthetic.upload(ctx, m)
 goals = synthetic.sample_valid_poses(val, m, G, seed=2000)[:, :2].copy()
-cnt = np.zeros((G, 16), dtype=np.uint64)
+cnt = np.zeros((G, 20), dtype=np.uint64)
 for it in range(2):
     ctx.timer_start()
     check(ctx.lib.pp_obstacle_heuristic_profile(ms.h, G, ptr(np.ascontiguousarray(goals)), ptr(cnt)))
@@ -29,12 +29,13 @@ names = ["init", "min", "partition", "sort", "offer", "push", "tail"]
 c = cnt.astype(np.float64)
 tot = c[:, :7].sum()
 print("goals %d  wall %.1f ms (incl. alloc/copies)" % (G, ms_))
-print("rounds/goal %.0f  mean window %.0f  mean padded sort size %.0f" % (c[:, 7].mean(), c[:, 8].sum() / c[:, 7].sum(), c[:, 9].sum() / c[:, 7].sum()))
+print("rounds/goal %.0f  mean window %.0f  rounds with the open list in HBM %.1f %%" % (c[:, 7].mean(), c[:, 8].sum() / c[:, 7].sum(), 100 * c[:, 9].sum() / c[:, 7].sum()))
 for i, nm in enumerate(names):
     print("  %-9s %5.1f %%  %.0f cycles/round" % (nm, 100 * c[:, i].sum() / tot, c[:, i].sum() / c[:, 7].sum()))
 print("cycles/goal %.3g" % (c[:, :7].sum(1).mean()))
 print("fallback rounds %.1f %%, their push phase %.1f %% of all cycles" % (100 * c[:, 10].sum() / c[:, 7].sum(), 100 * c[:, 11].sum() / tot))
 print("offer: store-wait %.0f  loads %.0f  count+barrier %.0f  (whole offer to end of insert %.0f) cycles/round" % tuple(c[:, k].sum() / c[:, 7].sum() for k in (12, 13, 14, 15)))
+print("push (cumulative): look-up %.0f  slot scan %.0f  stores %.0f cycles/round" % tuple(c[:, k].sum() / c[:, 7].sum() for k in (16, 17, 18)))
 G2 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 if G2:
     goals2 = synthetic.sample_valid_poses(val, m, G2, seed=2001)[:, :2].copy()
