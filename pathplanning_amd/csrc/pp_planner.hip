@@ -45,6 +45,15 @@ struct PathRec {
 };
 static_assert(sizeof(PathRec) == 40, "PathRec layout");
 
+/// A query handed from the four-queries-per-wave kernel to the one-query-per-wave kernel after its first
+/// `suspendAfter` expansions: everything that is not already in the slot's node / heap / key-map / engine buffers.
+struct SuspendRec {
+	int32_t q, slot;
+	int32_t heapSize, nNodes, nExpanded, nRngDraws, nRsAttempts, nRsLog, mtIdx;
+	uint32_t seq;
+	long long stateChecks, pathChecks; // totals so far (arcs + Reeds-Shepp)
+};
+
 struct RsLogEntry {
 	int32_t node, word;
 	double t, u, v;
@@ -82,6 +91,8 @@ struct SearchArgs {
 	float rsRev, rsFwd, rsSw; // Reeds-Shepp cost weights as floats (reeds_shepp.cpp:654)
 	int maxNodes;
 	int maxPath; // PathRec entries per query
+	int suspendAfter; // rows kernel: expansions after which a query moves to the one-query-per-wave kernel (0 = never)
+	int extraSlots;   // buffer slots beyond the rows' own, taken by rows whose query was suspended
 	size_t cells;
 	int64_t fieldElems; // floats per query in costFields (8 x 8-tiled obstacle-heuristic field)
 };
@@ -157,11 +168,16 @@ template <bool kProfile>
 __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(SearchArgs A, int nQueries, const double* __restrict__ starts, const double* __restrict__ goals,
 	const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase, HeapEntry* __restrict__ heapBase,
 	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, PathRec* __restrict__ pathBase,
-	DevResult* __restrict__ results, unsigned long long* __restrict__ prof)
+	DevResult* __restrict__ results, unsigned long long* __restrict__ prof, const SuspendRec* __restrict__ resume, const int* __restrict__ nResume,
+	const unsigned long long* __restrict__ mtBase)
 {
-	const int q = blockIdx.x;
-	if (q >= nQueries)
+	// Two uses: (a) one block per query of the batch, buffers indexed by the query (resume == nullptr);
+	// (b) continuation of the queries the rows kernel suspended: one block per SuspendRec, buffers indexed by its slot.
+	if (resume ? ((int)blockIdx.x >= *nResume || (int)blockIdx.x >= A.extraSlots) : (int)blockIdx.x >= nQueries)
 		return;
+	const SuspendRec rec = resume ? resume[blockIdx.x] : SuspendRec {};
+	const int q = resume ? rec.q : (int)blockIdx.x;
+	const size_t slot = resume ? (size_t)rec.slot : (size_t)q;
 	const int lane = threadIdx.x;
 	unsigned long long phase[PH_COUNT] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	unsigned long long tlast = 0;
@@ -187,9 +203,9 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	const MapView& m = A.m;
 	const int P = A.prims.n;
 	const int maxNodes = A.maxNodes;
-	Node* nodes = nodesBase + (size_t)q * maxNodes;
-	HeapEntry* heap = heapBase + (size_t)q * maxNodes;
-	uint32_t* keymap = keymapBase + (size_t)q * A.ks.size();
+	Node* nodes = nodesBase + slot * maxNodes;
+	HeapEntry* heap = heapBase + slot * maxNodes;
+	uint32_t* keymap = keymapBase + slot * A.ks.size();
 	uint32_t* expanded = expandedBase + (size_t)q * maxNodes;
 	RsLogEntry* rsLog = rsLogBase + (size_t)q * kRsLogCap;
 	const float* field = costFields + (size_t)q * A.fieldElems;
@@ -198,8 +214,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	const Pose start = { starts[3 * q], starts[3 * q + 1], wrap_theta(starts[3 * q + 2]) };
 	const Pose goal = { goals[3 * q], goals[3 * q + 1], wrap_theta(goals[3 * q + 2]) };
 
-	// ---- InitializeSearch, a_star.h:350-364
-	{
+	// ---- InitializeSearch, a_star.h:350-364 (a resumed query finds its key map, nodes and heap in the slot)
+	if (!resume) {
 		const size_t n = A.ks.size();
 		const size_t n4 = n / 4;
 		if ((((uintptr_t)keymap) & 15) == 0) {
@@ -221,19 +237,26 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	int pfNode = -1;
 	uint32_t pfWord = 0u;
 	bool pfDead = false; // the prefetched node was replaced (ProcessPossibleShortcut) after it was fetched
-	if (lane == 0)
-		Mt64::seed(mt, seeds[q]);
+	if (!resume) {
+		if (lane == 0)
+			Mt64::seed(mt, seeds[q]);
+	} else {
+		for (int i = lane; i < Mt64::N; i += 64)
+			mt[i] = mtBase[slot * Mt64::N + i]; // the engine state the rows kernel left in the slot
+	}
 	FrontLane front;
 	front_clear(front);
 	int frontCount = 0;
-	int heapSize = 0;
+	int heapSize = resume ? rec.heapSize : 0;
 	HeapEntry heapTop;
 	heapTop.ckey = ~0ull;
 	heapTop.nseq = ~0u;
 	heapTop.node = 0;
-	int nNodes = 1;
-	unsigned int seq = 1;
-	{
+	if (resume && heapSize > 0)
+		heapTop = heap[0]; // the whole open list was flushed into the heap when the query was suspended
+	int nNodes = resume ? rec.nNodes : 1;
+	unsigned int seq = resume ? rec.seq : 1;
+	if (!resume) {
 		double rs_, rc_;
 		sincos(start.t, &rs_, &rc_);
 		int ix, iy, it;
@@ -266,11 +289,13 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		HeapEntry sp;
 		front_insert(front, frontCount, e, lane, sp);
 	}
-	int mtIdx = Mt64::N; // engine freshly seeded: first draw twists
+	int mtIdx = resume ? rec.mtIdx : Mt64::N; // engine freshly seeded: first draw twists
 	__syncthreads();
 
-	int nExpanded = 0, nRngDraws = 0, nRsAttempts = 0, nRsLog = 0;
-	long long laneStateChecks = 0, lanePathChecks = 0; // this lane's arcs
+	int nExpanded = resume ? rec.nExpanded : 0, nRngDraws = resume ? rec.nRngDraws : 0, nRsAttempts = resume ? rec.nRsAttempts : 0,
+		nRsLog = resume ? rec.nRsLog : 0;
+	// this lane's arcs; the totals of the suspended part ride in lane 0
+	long long laneStateChecks = resume && lane == 0 ? rec.stateChecks : 0, lanePathChecks = resume && lane == 0 ? rec.pathChecks : 0;
 	long long rsStateChecks = 0, rsPathChecks = 0;     // wave-uniform (Reeds-Shepp children)
 	int status = -1, solutionNode = -1;
 	double solutionCost = __builtin_huge_val();
@@ -848,7 +873,8 @@ struct pp_planner {
 	unsigned long long* prof = nullptr; // diagnostic phase cycles, [maxBatch][PH_COUNT]
 	bool profile = false;
 	unsigned long long* mtStates = nullptr; // [searchRows][312] mt19937_64 engine state per row (rows kernel)
-	int* nextQuery = nullptr;               // query counter of the persistent rows kernel
+	int* nextQuery = nullptr;               // {query counter of the persistent rows kernel, spare slots handed out}
+	SuspendRec* suspended = nullptr;        // [extraSlots] queries handed over to the one-query-per-wave kernel
 	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
 	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
 	bool rowsKernel = false;                // four-queries-per-wave kernel (throughput) vs one query per wave (latency)
@@ -870,7 +896,7 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
-	void* ptrs[] = { p->paths, p->mtStates, p->nextQuery, p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->suspended, p->paths, p->mtStates, p->nextQuery, p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -1023,6 +1049,15 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		if (wanted < rows)
 			rows = wanted;
 		p->searchRows = (rows + kRowsPerWave - 1) / kRowsPerWave * kRowsPerWave;
+		// Very long queries leave the rows kernel after `suspendAfter` expansions and are finished one per wave (14 instead
+		// of ~25 us per expansion): a batch ends with its longest query (65 k expansions when a goal is unreachable for
+		// the car).  The rows kernel is the more efficient one per expansion, so only the extreme tail moves: with eight
+		// batches in flight 32768 measured best (10.2 k plans/s; 8192: 8.0 k; never: 9.8 k).
+		// PP_SEARCH_SUSPEND_AFTER=0 keeps every query in the rows kernel.
+		const char* cap = getenv("PP_SEARCH_SUSPEND_AFTER");
+		A.suspendAfter = p->rowsKernel ? (cap ? atoi(cap) : 32768) : 0;
+		const char* ex = getenv("PP_SEARCH_EXTRA_SLOTS");
+		A.extraSlots = A.suspendAfter > 0 ? (ex ? atoi(ex) : (max_batch + 15) / 16) : 0; // queries that may be handed over (the rest stays)
 	}
 	hipError_t e = hipSuccess;
 	auto alloc = [&](void** ptr, size_t bytes) {
@@ -1034,9 +1069,10 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->wfWorkspace, (size_t)p->wfBytesPerSlot * p->wfSlots);
 	alloc((void**)&p->wfError, 8);
 	// search buffers: one set per resident row (rows kernel) or per query (one-query-per-wave kernel)
-	const size_t S = p->rowsKernel ? (size_t)p->searchRows : B;
+	const size_t S = p->rowsKernel ? (size_t)p->searchRows + (size_t)A.extraSlots : B;
+	alloc((void**)&p->suspended, (A.extraSlots > 0 ? (size_t)A.extraSlots : 1) * sizeof(SuspendRec));
 	alloc((void**)&p->mtStates, (p->rowsKernel ? S : 1) * Mt64::N * sizeof(unsigned long long));
-	alloc((void**)&p->nextQuery, sizeof(int));
+	alloc((void**)&p->nextQuery, 2 * sizeof(int));
 	alloc((void**)&p->goalCells, B * 4);
 	alloc((void**)&p->nodes, S * N * sizeof(Node));
 	alloc((void**)&p->heaps, S * N * sizeof(HeapEntry));
@@ -1130,23 +1166,32 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	hipLaunchKernelGGL(k_goal_cells, dim3((n_queries + 255) / 256), dim3(256), 0, s, m, n_queries, goals_dev, planner->goalCells);
 	PP_HIP_TRY(hipGetLastError());
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
+	static const int dbgSkip = getenv("PP_DEBUG_SKIP") ? atoi(getenv("PP_DEBUG_SKIP")) : 0; // timing experiments only: 1 = no wavefront, 2 = no search
+	if (dbgSkip != 1)
 	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, planner->goalCells, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
 		planner->wfError, nullptr, /*tiledOut=*/true));
 	PP_HIP_TRY(hipEventRecord(planner->e1, s));
-	if (planner->rowsKernel) {
+	if (dbgSkip == 2) {
+	} else if (planner->rowsKernel) {
 		// four queries per wave, taken from a counter by a persistent grid (pp_planner_rows.hpp)
-		PP_HIP_TRY(hipMemsetAsync(planner->nextQuery, 0, sizeof(int), s));
+		PP_HIP_TRY(hipMemsetAsync(planner->nextQuery, 0, 2 * sizeof(int), s));
 		const int wavesWanted = (n_queries + kRowsPerWave - 1) / kRowsPerWave;
 		const int wavesMax = planner->searchRows / kRowsPerWave;
 		const int grid = wavesWanted < wavesMax ? wavesWanted : wavesMax;
 		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(grid), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
-			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, planner->nextQuery);
+			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, planner->nextQuery,
+			planner->suspended);
+		PP_HIP_TRY(hipGetLastError());
+		if (planner->args.extraSlots > 0) // the queries it handed over: one wave each, the block count is read on the device
+			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.extraSlots), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
+				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
+				planner->suspended, planner->nextQuery + 1, planner->mtStates);
 	} else if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof);
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr);
 	else
 		hipLaunchKernelGGL(k_hybrid_search<false>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof);
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr);
 	PP_HIP_TRY(hipGetLastError());
 	PP_HIP_TRY(hipEventRecord(planner->e2, s));
 	planner->lastBatch = n_queries;

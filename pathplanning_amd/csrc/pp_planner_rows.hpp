@@ -23,18 +23,22 @@
 __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_rows(SearchArgs A, int nQueries, const double* __restrict__ starts,
 	const double* __restrict__ goals, const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase,
 	HeapEntry* __restrict__ heapBase, uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase,
-	PathRec* __restrict__ pathBase, unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery)
+	PathRec* __restrict__ pathBase, unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery,
+	SuspendRec* __restrict__ suspended)
 {
 	const int lane = threadIdx.x;
 	const int rl = lane & (kRowLanes - 1);
 	const int sb = (lane >> 4) * kRowSlots; // first staging slot of this row
 	// search buffers (node records, heap, key map, engine state) belong to the ROW, not to the query: the row's
 	// queries use them one after the other, so a planner needs them for its resident rows only
-	const size_t slot = (size_t)blockIdx.x * kRowsPerWave + (size_t)(lane >> 4);
-	Node* const nodes = nodesBase + slot * A.maxNodes;
-	HeapEntry* const heap = heapBase + slot * A.maxNodes;
-	uint32_t* const keymap = keymapBase + slot * A.ks.size();
-	unsigned long long* const mt = mtBase + slot * Mt64::N;
+	// (a row that hands its query over to the one-query-per-wave kernel leaves the slot to it and takes a spare one)
+	size_t slot = (size_t)blockIdx.x * kRowsPerWave + (size_t)(lane >> 4);
+	Node* nodes = nodesBase + slot * A.maxNodes;
+	HeapEntry* heap = heapBase + slot * A.maxNodes;
+	uint32_t* keymap = keymapBase + slot * A.ks.size();
+	unsigned long long* mt = mtBase + slot * Mt64::N;
+	const int rowsTotal = (int)gridDim.x * kRowsPerWave;
+	bool noSuspend = false; // no spare slot was left for this query
 
 	// staging of the children of the node being expanded (per row); kept until the next expansion so that a child popped
 	// right away is read back from LDS instead of HBM
@@ -178,6 +182,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				rsNode = -1;
 				pfNode = -1;
 				pfDead = false;
+				noSuspend = false;
 				front_clear(front);
 				frontCount = 0;
 				heapSize = 0;
@@ -242,6 +247,54 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 		}
 		if (nSpill > 0)
 			flush_spills();
+		if (A.suspendAfter > 0 && nExpanded >= A.suspendAfter && !noSuspend) {
+			// ---- hand the query over: its open list goes entirely into the heap, the scalars into a SuspendRec; the row
+			// continues with the next query in a spare slot (nextQuery[1] counts the spare slots handed out)
+			int ns = 0;
+			if (rl == 0)
+				ns = atomicAdd(nextQuery + 1, 1);
+			ns = (int)row_read((uint32_t)ns, lane, 0);
+			if (ns >= A.extraSlots) {
+				noSuspend = true;
+			} else {
+				if (rl < frontCount) {
+					HeapEntry e;
+					e.ckey = front.ckey;
+					e.nseq = front.nseq;
+					e.node = front.node;
+					spillBuf[rl] = e;
+				}
+				nSpill = frontCount;
+				frontCount = 0;
+				if (nSpill > 0)
+					flush_spills();
+				const long long sc = row_sum_i64(laneStateChecks, lane) + rsStateChecks, pc = row_sum_i64(lanePathChecks, lane) + rsPathChecks;
+				if (rl == 0) {
+					SuspendRec r;
+					r.q = q;
+					r.slot = (int32_t)slot;
+					r.heapSize = heapSize;
+					r.nNodes = nNodes;
+					r.nExpanded = nExpanded;
+					r.nRngDraws = nRngDraws;
+					r.nRsAttempts = nRsAttempts;
+					r.nRsLog = nRsLog;
+					r.mtIdx = mtIdx;
+					r.seq = seq;
+					r.stateChecks = sc;
+					r.pathChecks = pc;
+					suspended[ns] = r;
+				}
+				slot = (size_t)rowsTotal + (size_t)ns;
+				nodes = nodesBase + slot * A.maxNodes;
+				heap = heapBase + slot * A.maxNodes;
+				keymap = keymapBase + slot * A.ks.size();
+				mt = mtBase + slot * Mt64::N;
+				wave_vmem_sync();
+				act = false;
+				continue;
+			}
+		}
 		HeapEntry top;
 		const bool fromFront = frontCount > 0 && (heapSize == 0 || key_before(row_read64(front.ckey, lane, 0), row_read(front.nseq, lane, 0), heapTop.ckey, heapTop.nseq));
 		if (fromFront) {
