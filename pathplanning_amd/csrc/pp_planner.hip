@@ -106,15 +106,6 @@ struct DevResult {
 constexpr uint32_t kExplored = 0xFFFFFFFFu;
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 
-__global__ void k_goal_cells(MapView m, int n, const double* __restrict__ goals, int32_t* __restrict__ cells)
-{
-	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n)
-		return;
-	int row, col;
-	world_to_cell(m, goals[3 * i], goals[3 * i + 1], row, col);
-	cells[i] = inside_map(m, row, col) ? row * m.cols + col : -1; // WorldPositionToGridCell(bounded), heuristics.cpp:115
-}
 
 // kProfile: diagnostic build only -- accumulates shader-clock cycles per phase into `prof`
 // (8 words per query); the product path launches kProfile = false, where no stamp executes.
@@ -863,7 +854,6 @@ struct pp_planner {
 	int64_t wfBytesPerSlot = 0;
 	int wfSlots = 0;
 	int32_t* wfError = nullptr;
-	int32_t* goalCells = nullptr;
 	Node* nodes = nullptr;
 	HeapEntry* heaps = nullptr;
 	uint32_t* keymaps = nullptr;
@@ -873,7 +863,7 @@ struct pp_planner {
 	unsigned long long* prof = nullptr; // diagnostic phase cycles, [maxBatch][PH_COUNT]
 	bool profile = false;
 	unsigned long long* mtStates = nullptr; // [searchRows][312] mt19937_64 engine state per row (rows kernel)
-	int* nextQuery = nullptr;               // {query counter of the persistent rows kernel, spare slots handed out}
+	int* nextQuery = nullptr;               // = wfError + 2: {query counter of the persistent rows kernel, spare slots handed out}
 	SuspendRec* suspended = nullptr;        // [extraSlots] queries handed over to the one-query-per-wave kernel
 	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
 	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
@@ -896,7 +886,7 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
-	void* ptrs[] = { p->suspended, p->paths, p->mtStates, p->nextQuery, p->table, p->costFields, p->wfWorkspace, p->wfError, p->goalCells, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -1067,13 +1057,11 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->table, tableBytes);
 	alloc((void**)&p->costFields, B * (size_t)A.fieldElems * sizeof(float));
 	alloc((void**)&p->wfWorkspace, (size_t)p->wfBytesPerSlot * p->wfSlots);
-	alloc((void**)&p->wfError, 8);
+	alloc((void**)&p->wfError, 16); // control block: {wavefront error flag, wavefront goal counter, search query counter, spare slots used}
 	// search buffers: one set per resident row (rows kernel) or per query (one-query-per-wave kernel)
 	const size_t S = p->rowsKernel ? (size_t)p->searchRows + (size_t)A.extraSlots : B;
 	alloc((void**)&p->suspended, (A.extraSlots > 0 ? (size_t)A.extraSlots : 1) * sizeof(SuspendRec));
 	alloc((void**)&p->mtStates, (p->rowsKernel ? S : 1) * Mt64::N * sizeof(unsigned long long));
-	alloc((void**)&p->nextQuery, 2 * sizeof(int));
-	alloc((void**)&p->goalCells, B * 4);
 	alloc((void**)&p->nodes, S * N * sizeof(Node));
 	alloc((void**)&p->heaps, S * N * sizeof(HeapEntry));
 	alloc((void**)&p->keymaps, S * A.ks.size() * 4);
@@ -1096,6 +1084,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		return pph::hip_fail(e, "planner allocation");
 	}
 	A.heur.table = p->table;
+	p->nextQuery = p->wfError + 2;
 	p->nh.nx = dims[0];
 	*out = p;
 	return PP_OK;
@@ -1161,20 +1150,17 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	hipStream_t s = planner->map->ctx->stream;
 	planner->args.m = planner->map->view(); // validator tunables may have changed
 	const MapView& m = planner->args.m;
-	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 8, s));
+	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 16, s)); // the step's only fill: every counter of both kernels
 	PP_HIP_TRY(hipEventRecord(planner->e0, s));
-	hipLaunchKernelGGL(k_goal_cells, dim3((n_queries + 255) / 256), dim3(256), 0, s, m, n_queries, goals_dev, planner->goalCells);
-	PP_HIP_TRY(hipGetLastError());
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
 	static const int dbgSkip = getenv("PP_DEBUG_SKIP") ? atoi(getenv("PP_DEBUG_SKIP")) : 0; // timing experiments only: 1 = no wavefront, 2 = no search
 	if (dbgSkip != 1)
-	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, planner->goalCells, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
-		planner->wfError, nullptr, /*tiledOut=*/true));
+	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
+		planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true));
 	PP_HIP_TRY(hipEventRecord(planner->e1, s));
 	if (dbgSkip == 2) {
 	} else if (planner->rowsKernel) {
 		// four queries per wave, taken from a counter by a persistent grid (pp_planner_rows.hpp)
-		PP_HIP_TRY(hipMemsetAsync(planner->nextQuery, 0, 2 * sizeof(int), s));
 		const int wavesWanted = (n_queries + kRowsPerWave - 1) / kRowsPerWave;
 		const int wavesMax = planner->searchRows / kRowsPerWave;
 		const int grid = wavesWanted < wavesMax ? wavesWanted : wavesMax;

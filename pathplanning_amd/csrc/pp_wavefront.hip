@@ -575,7 +575,7 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 template <bool kProfile>
 __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapView m, int nGoals, const int32_t* __restrict__ goalCells, float* __restrict__ costOut,
 	void* workspace, int64_t bytesPerSlot, uint32_t fcap, uint32_t gcap, int32_t* errorFlag, unsigned long long* __restrict__ prof, int* __restrict__ goalCounter,
-	int tiledOut)
+	int tiledOut, const double* __restrict__ goalPoses)
 {
 	unsigned long long ph[WP_COUNT];
 	unsigned long long tl = 0;
@@ -662,7 +662,14 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			}
 			reinterpret_cast<unsigned long long*>(state)[t] = v;
 		}
-		const int32_t start = goalCells[g];
+		int32_t start;
+		if (goalPoses) { // (x, y, theta) triples: WorldPositionToGridCell(bounded), heuristics.cpp:115
+			int row, col;
+			world_to_cell(m, goalPoses[3 * g], goalPoses[3 * g + 1], row, col);
+			start = inside_map(m, row, col) ? row * m.cols + col : -1;
+		} else {
+			start = goalCells[g];
+		}
 		if (tid == 0) {
 			s_min = 0u; // cost bits of the start cell
 			s_minNext[0] = 0xFFFFFFFFu;
@@ -1206,7 +1213,7 @@ int wavefront_resident_blocks()
 }
 
 hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
-	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev, bool tiledOut)
+	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev, bool tiledOut, const double* goalPosesDev, bool countersZeroed)
 {
 	if (nGoals <= 0)
 		return hipSuccess;
@@ -1214,15 +1221,17 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 	wf_caps(m.rows, m.cols, fcap, gcap);
 	int grid = nGoals < nSlots ? nGoals : nSlots;
 	// errorFlagDev[0] = overflow flag, errorFlagDev[1] = next-goal counter
-	hipError_t e = hipMemsetAsync(errorFlagDev + 1, 0, sizeof(int), s);
-	if (e != hipSuccess)
-		return e;
+	if (!countersZeroed) {
+		hipError_t e = hipMemsetAsync(errorFlagDev + 1, 0, sizeof(int), s);
+		if (e != hipSuccess)
+			return e;
+	}
 	if (profDev)
 		hipLaunchKernelGGL(k_wavefront<true>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0);
+			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev);
 	else
 		hipLaunchKernelGGL(k_wavefront<false>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0);
+			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev);
 	return hipGetLastError();
 }
 

@@ -5,8 +5,8 @@ TAG=${1:-insts}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc_$TAG
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $OUT/a -o run -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline > $OUT/a.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/b -o run -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline > $OUT/b.log 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $OUT/a -o run -- python3 bench.py ${PMC_BENCH_ARGS:---steps 1 --warmup 0 --streams 1} --no-cpu-baseline > $OUT/a.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/b -o run -- python3 bench.py ${PMC_BENCH_ARGS:---steps 1 --warmup 0 --streams 1} --no-cpu-baseline > $OUT/b.log 2>&1 || true
 python3 - <<PY
 import csv, glob, re
 agg = {}
