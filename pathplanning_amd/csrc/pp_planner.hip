@@ -865,6 +865,7 @@ struct pp_planner {
 	unsigned long long* mtStates = nullptr; // [searchRows][312] mt19937_64 engine state per row (rows kernel)
 	int* nextQuery = nullptr;               // = wfError + 2: {query counter of the persistent rows kernel, spare slots handed out}
 	SuspendRec* suspended = nullptr;        // [extraSlots] queries handed over to the one-query-per-wave kernel
+	int32_t* order = nullptr;               // [maxBatch] query indices, probable longest first (rows kernel)
 	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
 	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
 	bool rowsKernel = false;                // four-queries-per-wave kernel (throughput) vs one query per wave (latency)
@@ -886,7 +887,7 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
-	void* ptrs[] = { p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -1066,6 +1067,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->heaps, S * N * sizeof(HeapEntry));
 	alloc((void**)&p->keymaps, S * A.ks.size() * 4);
 	alloc((void**)&p->expanded, B * N * 4);
+	alloc((void**)&p->order, B * 4);
 	alloc((void**)&p->paths, B * (size_t)A.maxPath * sizeof(PathRec));
 	alloc((void**)&p->rsLogs, B * kRsLogCap * sizeof(RsLogEntry));
 	alloc((void**)&p->results, B * sizeof(DevResult));
@@ -1164,9 +1166,13 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		const int wavesWanted = (n_queries + kRowsPerWave - 1) / kRowsPerWave;
 		const int wavesMax = planner->searchRows / kRowsPerWave;
 		const int grid = wavesWanted < wavesMax ? wavesWanted : wavesMax;
+		static const bool lpt = !(getenv("PP_SEARCH_ORDER") && getenv("PP_SEARCH_ORDER")[0] == '0');
+		const bool ordered = lpt && n_queries <= kOrderMax && n_queries > planner->searchRows;
+		if (ordered)
+			hipLaunchKernelGGL(k_order_queries, dim3(1), dim3(1024), 0, s, planner->args, n_queries, starts_dev, planner->costFields, planner->order);
 		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(grid), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
 			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, planner->nextQuery,
-			planner->suspended);
+			planner->suspended, ordered ? planner->order : nullptr);
 		PP_HIP_TRY(hipGetLastError());
 		if (planner->args.extraSlots > 0) // the queries it handed over: one wave each, the block count is read on the device
 			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.extraSlots), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
