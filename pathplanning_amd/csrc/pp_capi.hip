@@ -76,6 +76,40 @@ int check_map(pp_map* map, bool needDist)
 
 } // namespace
 
+namespace pph {
+void ctx_release(pp_ctx* ctx)
+{
+	if (!ctx || __atomic_sub_fetch(&ctx->refs, 1, __ATOMIC_ACQ_REL) > 0)
+		return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->ev0)
+		(void)hipEventDestroy(ctx->ev0);
+	if (ctx->ev1)
+		(void)hipEventDestroy(ctx->ev1);
+	if (ctx->ownsStream && ctx->stream)
+		(void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+void map_release(pp_map* map)
+{
+	if (!map || __atomic_sub_fetch(&map->refs, 1, __ATOMIC_ACQ_REL) > 0)
+		return;
+	(void)hipSetDevice(map->ctx->device);
+	(void)hipStreamSynchronize(map->ctx->stream);
+	if (map->d2)
+		(void)hipFree(map->d2);
+	if (map->dist)
+		(void)hipFree(map->dist);
+	if (map->pathcost)
+		(void)hipFree(map->pathcost);
+	if (map->occ8)
+		(void)hipFree(map->occ8);
+	pp_ctx* ctx = map->ctx;
+	delete map;
+	ctx_release(ctx);
+}
+} // namespace pph
+
 extern "C" {
 
 const char* pp_last_error(void) { return g_lastError.c_str(); }
@@ -123,16 +157,7 @@ int pp_ctx_create(int device, void* stream, pp_ctx** out)
 
 int pp_ctx_destroy(pp_ctx* ctx)
 {
-	if (!ctx)
-		return PP_OK;
-	(void)hipSetDevice(ctx->device);
-	if (ctx->ev0)
-		(void)hipEventDestroy(ctx->ev0);
-	if (ctx->ev1)
-		(void)hipEventDestroy(ctx->ev1);
-	if (ctx->ownsStream && ctx->stream)
-		(void)hipStreamDestroy(ctx->stream);
-	delete ctx;
+	pph::ctx_release(ctx);
 	return PP_OK;
 }
 
@@ -182,6 +207,7 @@ int pp_map_create(pp_ctx* ctx, const pp_map_desc* desc, pp_map** out)
 	PP_HIP_TRY(hipSetDevice(ctx->device));
 	auto m = std::make_unique<pp_map>();
 	m->ctx = ctx;
+	__atomic_add_fetch(&ctx->refs, 1, __ATOMIC_RELAXED); // the map keeps its context alive
 	m->desc = *desc;
 	*out = m.release();
 	return PP_OK;
@@ -189,19 +215,7 @@ int pp_map_create(pp_ctx* ctx, const pp_map_desc* desc, pp_map** out)
 
 int pp_map_destroy(pp_map* map)
 {
-	if (!map)
-		return PP_OK;
-	(void)hipSetDevice(map->ctx->device);
-	(void)hipStreamSynchronize(map->ctx->stream);
-	if (map->d2)
-		(void)hipFree(map->d2);
-	if (map->dist)
-		(void)hipFree(map->dist);
-	if (map->pathcost)
-		(void)hipFree(map->pathcost);
-	if (map->occ8)
-		(void)hipFree(map->occ8);
-	delete map;
+	pph::map_release(map);
 	return PP_OK;
 }
 

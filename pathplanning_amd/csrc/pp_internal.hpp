@@ -76,7 +76,18 @@ hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, co
 
 } // namespace pph
 
+struct pp_ctx;
+struct pp_map;
+namespace pph {
+void ctx_release(pp_ctx* ctx); // drops one reference, frees at zero
+void map_release(pp_map* map);
+} // namespace pph
+
+// Lifetimes: a map keeps its context alive and a planner its map (reference counts), so the handles may be destroyed
+// in any order -- e.g. by a garbage collector that finalises a reference cycle in arbitrary order.  pp_*_destroy drops
+// the caller's reference; the object goes when the last dependent has gone.
 struct pp_ctx {
+	int refs = 1;
 	int device = 0;
 	hipStream_t stream = nullptr;
 	bool ownsStream = false;
@@ -84,6 +95,7 @@ struct pp_ctx {
 };
 
 struct pp_map {
+	int refs = 1;
 	pp_ctx* ctx = nullptr;
 	pp_map_desc desc {};
 	float minSafeRadius = 1.0f, minInterp = 0.1f;

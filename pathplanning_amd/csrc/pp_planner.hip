@@ -898,7 +898,9 @@ void free_planner(pp_planner* p)
 		(void)hipEventDestroy(p->e1);
 	if (p->e2)
 		(void)hipEventDestroy(p->e2);
+	pp_map* map = p->map;
 	delete p;
+	pph::map_release(map); // the planner kept its map (and through it the context) alive
 }
 
 } // namespace
@@ -923,6 +925,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	PP_HIP_TRY(hipSetDevice(map->ctx->device));
 	auto* p = new pp_planner();
 	p->map = map;
+	__atomic_add_fetch(&map->refs, 1, __ATOMIC_RELAXED);
 	p->params = *params;
 	p->maxBatch = max_batch;
 	p->maxNodes = max_nodes_per_query;

@@ -1,0 +1,110 @@
+"""-m gpu: BASELINE configs[3] at full size (4096 queries on one 1024 x 1024 map) through properties that do not need
+the oracle for every query: permutation invariance, path geometry and validity, cost bookkeeping -- plus exact oracle
+agreement on a random sample.  Exercises the throughput configuration of the planner (rows kernel, queries taken
+longest-first, hand-over of very long queries)."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def arc_end(p, kappa, d, backward):
+    """KinematicBicycleModel::ConstantSteer with rearToCenter = 0 (models/kinematic_bicycle_model.cpp:5-32)."""
+    x, y, t = p
+    dd = -d if backward else d
+    if abs(kappa) <= 1e-9:
+        return np.array([x + dd * math.cos(t), y + dd * math.sin(t), t])
+    t1 = t + dd * kappa
+    return np.array([x + (math.sin(t1) - math.sin(t)) / kappa, y - (math.cos(t1) - math.cos(t)) / kappa, t1])
+
+
+def test_full_size_batch_properties():
+    import pathplanning_amd as pa
+    from pathplanning_amd import synthetic
+    B = 4096
+    ctx = pa.Context(0)
+    m = synthetic.make_map(1024, 24, seed=1)
+    ms, val = synthetic.upload(ctx, m)
+    params = pa.HybridAStarSearchParameters()
+    planner = pa.HybridAStarBatch(val, params, max_batch=B, max_nodes=81920, search_rows=1024)
+    assert planner.search_rows == 1024  # the four-queries-per-wave kernel, four queries per row on average
+    planner.initialize()
+    reach = synthetic.reachable_mask(val, m)
+    starts = synthetic.sample_valid_poses(val, m, B, seed=1000, reachable=reach)
+    goals = synthetic.sample_valid_poses(val, m, B, seed=2000, reachable=reach)
+    seeds = np.arange(B, dtype=np.uint64)
+    res = planner.search_batch(starts, goals, seeds)
+    status = np.array([r.status for r in res])
+    nexp = np.array([r.n_expanded for r in res])
+    cost = np.array([r.cost for r in res])
+    assert set(np.unique(status)) <= {0, -1}
+    assert (status == 0).mean() > 0.95
+    assert nexp.max() > 32768  # some queries went through the hand-over to the one-query-per-wave kernel
+
+    # ---- paths: geometry, validity, cost bookkeeping (every solved query)
+    half_pi_tol = 1e-3 * math.pi / 180.0
+    # primitive curvatures: p = 2 * deltaIndex + direction (hybrid_a_star.cpp:13-29,65-77)
+    delta_max = math.atan(params.wheelbase / params.min_turning_radius)
+    deltas = [0.0]
+    for i in range(params.num_generated_motion // 2):
+        d = (i + 1) / 2.0 * delta_max
+        deltas += [d, -d]
+    arc_len = 1.5 * params.spatial_resolution
+    checked_edges = 0
+    all_poses = []
+    for q in np.nonzero(status == 0)[0]:
+        path = planner.get_path_of(int(q))
+        poses, kind, prim, length = path["poses"], path["kind"], path["prim"], path["length"]
+        assert len(poses) == res[q].n_path >= 1
+        assert np.abs(poses[0, :2] - starts[q, :2]).max() < 1e-12 and kind[0] == 0
+        assert math.hypot(*(poses[-1, :2] - goals[q, :2])) < 1e-3  # IsSolution: IdenticalPoses with the goal
+        dth = (poses[-1, 2] - goals[q, 2] + math.pi) % (2 * math.pi) - math.pi
+        assert abs(dth) < half_pi_tol
+        total = 0.0
+        for i in range(1, len(poses)):
+            assert length[i] > 0
+            total += length[i]  # forward / reverse multipliers are 1, the Voronoi term is >= 0
+            if kind[i] == 1:
+                p = int(prim[i])
+                assert 0 <= p < planner.num_primitives and length[i] <= arc_len + 1e-12
+                kappa = math.tan(deltas[p // 2]) / params.wheelbase
+                want = arc_end(poses[i - 1], kappa, length[i], backward=(p % 2 == 1))
+                assert np.abs(want[:2] - poses[i, :2]).max() < 1e-9
+                dt = (want[2] - poses[i, 2] + math.pi) % (2 * math.pi) - math.pi
+                assert abs(dt) < 1e-9
+                checked_edges += 1
+            else:
+                assert kind[i] == 2 and i == len(poses) - 1  # the Reeds-Shepp child is the goal: last edge
+        assert cost[q] >= total * (1 - 1e-6)  # (a Reeds-Shepp edge's cost is computed in float, reeds_shepp.cpp:654)
+        all_poses.append(poses)
+    assert checked_edges > 50000
+    assert val.is_state_valid(np.concatenate(all_poses)).all()
+
+    # ---- permutation invariance: the same queries in another order (other rows, other hand-out order)
+    perm = np.random.RandomState(3).permutation(B)
+    res2 = planner.search_batch(starts[perm].copy(), goals[perm].copy(), seeds[perm].copy())
+    for f in ("status", "n_expanded", "n_nodes", "n_rng_draws", "n_rs_attempts", "n_state_checks", "n_path_checks", "n_path"):
+        a = np.array([getattr(r, f) for r in res])[perm]
+        b = np.array([getattr(r, f) for r in res2])
+        assert np.array_equal(a, b), f
+    assert np.array_equal(cost[perm], np.array([r.cost for r in res2]))
+
+    # ---- exact agreement with the oracle on a random sample (expansion order included)
+    ow = O.World(float(m["upper"][0]), float(m["upper"][1]), m["resolution"])
+    ow.set_occ(m["occ"])
+    ow.set_d2(m["d2"])
+    ow.set_pathcost(m["path_cost"])
+    h = O.Hybrid(ow, O.params_array(), table=planner.nonholo_table())
+    h.set_max_expansions(20000)
+    sample = [int(q) for q in np.random.RandomState(4).permutation(B) if nexp[q] < 20000][:48]
+    planner.search_batch(starts, goals, seeds)  # results of the original order again
+    for q in sample:
+        r = h.search(starts[q], goals[q], int(seeds[q]))
+        assert res[q].status == r["status"] and res[q].n_expanded == len(r["expanded"]) and res[q].n_nodes == r["n_nodes"]
+        assert np.array_equal(planner.get_expanded_of(q), r["expanded"])
+        if r["status"] == 0:
+            assert abs(res[q].cost - r["cost"]) < 1e-5

@@ -225,3 +225,22 @@ def test_long_queries_are_handed_over_to_the_one_query_kernel(monkeypatch):
     monkeypatch.setenv("PP_SEARCH_EXTRA_SLOTS", "64")  # every long query handed over
     planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=8)
     assert compare(planner, res, h, starts, goals, seeds) >= n // 2
+
+
+def test_handles_may_be_destroyed_in_any_order():
+    """A map keeps its context alive and a planner its map: destroying the context and the map first (what a garbage
+    collector may do with a reference cycle) must leave the planner usable."""
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    import pathplanning_amd as pa
+    planner = pa.HybridAStarBatch(val, pa.HybridAStarSearchParameters(), max_batch=2, max_nodes=16384)
+    planner.initialize()
+    lib = planner.lib
+    lib.pp_ctx_destroy(ctx.h)
+    ctx.h = None
+    lib.pp_map_destroy(ms.h)
+    ms.h = None
+    starts = np.array([[-10.0, -10.0, 0.0], [9.0, -9.0, 1.0]])
+    goals = np.array([[10.0, 10.0, 0.0], [-9.0, 8.0, -2.0]])
+    res = planner.search_batch(starts, goals, np.array([7, 8], dtype=np.uint64))
+    assert res[0].n_expanded > 0 and res[1].n_expanded > 0
+    planner.close()
