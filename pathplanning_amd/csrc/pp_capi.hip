@@ -43,6 +43,7 @@ ppd::MapView pp_map::view() const
 	v.dist = dist;
 	v.pathcost = pathcost;
 	v.occ8 = occ8;
+	v.validBits = validBits;
 	return v;
 }
 
@@ -104,6 +105,8 @@ void map_release(pp_map* map)
 		(void)hipFree(map->pathcost);
 	if (map->occ8)
 		(void)hipFree(map->occ8);
+	if (map->validBits)
+		(void)hipFree(map->validBits);
 	pp_ctx* ctx = map->ctx;
 	delete map;
 	ctx_release(ctx);
@@ -233,6 +236,9 @@ int pp_map_upload_dist2(pp_map* map, const int32_t* d2_host)
 		PP_HIP_TRY(hipMalloc((void**)&map->dist, n * sizeof(float)));
 	PP_HIP_TRY(hipMemcpyAsync(map->d2, d2_host, n * sizeof(int32_t), hipMemcpyHostToDevice, map->ctx->stream));
 	PP_HIP_TRY(launch_d2_to_distance(map->ctx->stream, map->d2, map->dist, (int64_t)n, map->desc.resolution));
+	if (!map->validBits)
+		PP_HIP_TRY(hipMalloc((void**)&map->validBits, ((n + 63) / 64) * 8)); // whole 64-cell groups: one ballot each
+	PP_HIP_TRY(launch_valid_bits(map->ctx->stream, map->dist, (int64_t)n, map->minSafeRadius, map->validBits));
 	PP_HIP_TRY(hipStreamSynchronize(map->ctx->stream));
 	return PP_OK;
 }
@@ -274,8 +280,13 @@ int pp_map_set_validator(pp_map* map, float min_safe_radius, float min_path_inte
 {
 	if (check_map(map, false))
 		return PP_ERR_INVALID;
+	const bool radiusChanged = !(map->minSafeRadius == min_safe_radius);
 	map->minSafeRadius = min_safe_radius;
 	map->minInterp = min_path_interpolation_distance;
+	if (radiusChanged && map->dist && map->validBits) { // the validity bitmap is the comparison against this radius
+		PP_HIP_TRY(hipSetDevice(map->ctx->device));
+		PP_HIP_TRY(launch_valid_bits(map->ctx->stream, map->dist, (int64_t)map->cells(), map->minSafeRadius, map->validBits));
+	}
 	return PP_OK;
 }
 

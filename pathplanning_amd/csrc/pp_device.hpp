@@ -44,6 +44,7 @@ struct MapView {
 	const float* dist;      // (float)(sqrt((double)d2) * res): GetDistanceToNearestObstacle, gvd.h:38
 	const float* pathcost;  // GVD::PathCostMap
 	const uint8_t* occ8;    // 1 = occupied
+	const uint32_t* validBits; // bit (row * cols + col): dist >= minSafeRadius, rebuilt when either changes (128 KiB at 1024^2)
 };
 
 /// geometry/2dplane.h:36-45
@@ -101,6 +102,27 @@ PPD_INLINE bool is_state_valid(const MapView& m, double x, double y, double thet
 		return false;
 	distance = m.dist[(size_t)row * m.cols + col];
 	return distance >= m.minSafeRadius;
+}
+
+/// Same test without the distance: the cell's answer comes from the validity bitmap (one bit per cell, the result of the
+/// identical float comparison), so a streamed check moves 24 B in + 1 B out and the 128 KiB bitmap stays in cache
+/// instead of a 4-byte gather that pulls a whole line of the 4 MiB distance grid per pose.
+PPD_INLINE bool is_state_valid_bit(const MapView& m, double x, double y, double theta)
+{
+	const double lx = x - m.lox, ly = y - m.loy;
+	const double lt = wrap_theta(theta);
+	int row, col;
+	world_to_cell(m, x, y, row, col);
+	if (lx < m.lbx || lx > m.ubx)
+		return false;
+	if (ly < m.lby || ly > m.uby)
+		return false;
+	if (lt < m.lbt || lt > m.ubt)
+		return false;
+	if (!inside_map(m, row, col))
+		return false;
+	const size_t cell = (size_t)row * m.cols + col;
+	return (m.validBits[cell >> 5] >> (cell & 31)) & 1u;
 }
 
 /// KinematicBicycleModel::ConstantSteer with rearToCenter = 0 (beta = 0, cos(beta) = 1),

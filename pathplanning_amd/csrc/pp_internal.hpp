@@ -57,6 +57,8 @@ hipError_t launch_rollout(hipStream_t s, const ppd::MapView& m, const RolloutPar
 	uint8_t* valid, double* pose, int32_t* key, double* cost, double* length);
 hipError_t launch_rs_solve(hipStream_t s, int64_t n, const double* from, const double* to, double rmin, float rev, float fwd, float sw, int32_t* word,
 	double* tuv, float* cost, double* segLength);
+/// bits[cell / 32] bit (cell % 32) = dist[cell] >= minSafeRadius
+hipError_t launch_valid_bits(hipStream_t s, const float* dist, int64_t cells, float minSafeRadius, uint32_t* bits);
 hipError_t launch_nonholo_build(hipStream_t s, const NonHoloDesc& d, double* table);
 hipError_t launch_knn(hipStream_t s, int64_t nPoints, const double* pts, int64_t nQueries, const double* q, int k, int32_t* idx, double* d2);
 
@@ -103,6 +105,7 @@ struct pp_map {
 	float* dist = nullptr;
 	float* pathcost = nullptr;
 	uint8_t* occ8 = nullptr;
+	uint32_t* validBits = nullptr; // one bit per cell: dist >= minSafeRadius
 	ppd::MapView view() const;
 	size_t cells() const { return (size_t)desc.rows * desc.cols; }
 };

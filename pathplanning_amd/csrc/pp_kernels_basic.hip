@@ -44,33 +44,59 @@ __global__ void k_occ_to_u8(const int32_t* __restrict__ occ, uint8_t* __restrict
 // One pose per thread.  A block stages its 256 poses (6 KiB, contiguous in the
 // Pose2d AoS layout) through LDS with 16-byte coalesced loads, so HBM sees whole
 // lines once; the distance grid is a cached gather (4 MiB at 1024^2: L2 resident).
+#ifndef PP_CS_PER
+#define PP_CS_PER 4
+#endif
+constexpr int kCsPer = PP_CS_PER; // poses per thread and tile: 4 x 256 x 24 B = 24 KiB in flight per workgroup before the barrier
 __global__ void __launch_bounds__(kBlock) k_check_states(MapView m, int64_t n, const double* __restrict__ poses, uint8_t* __restrict__ valid, int aligned16)
 {
-	__shared__ double2 tile[kBlock * 3 / 2];
-	const int64_t nTiles = (n + kBlock - 1) / kBlock;
+	constexpr int kTile = kBlock * kCsPer;
+	__shared__ double2 tile[kTile * 3 / 2];
+	const int64_t nTiles = (n + kTile - 1) / kTile;
 	for (int64_t tileIdx = blockIdx.x; tileIdx < nTiles; tileIdx += gridDim.x) {
-		const int64_t base = tileIdx * kBlock;
-		const int count = (int)min((int64_t)kBlock, n - base);
+		const int64_t base = tileIdx * kTile;
+		const int count = (int)min((int64_t)kTile, n - base);
 		const double* src = poses + base * 3;
 		const int nd = count * 3; // doubles in this tile
-		if (count == kBlock && aligned16) {
+		if (count == kTile && aligned16) {
 			const double2* src2 = reinterpret_cast<const double2*>(src); // base*24 bytes is 16-byte aligned
-			tile[threadIdx.x] = src2[threadIdx.x];
-			if (threadIdx.x < kBlock / 2)
-				tile[kBlock + threadIdx.x] = src2[kBlock + threadIdx.x];
+			double2 v[kCsPer * 3 / 2];
+#pragma unroll
+			for (int k = 0; k < kCsPer * 3 / 2; k++)
+				v[k] = src2[k * kBlock + threadIdx.x]; // all loads of the tile are in flight together
+#pragma unroll
+			for (int k = 0; k < kCsPer * 3 / 2; k++)
+				tile[k * kBlock + threadIdx.x] = v[k];
 		} else {
 			double* t = reinterpret_cast<double*>(tile);
 			for (int i = threadIdx.x; i < nd; i += kBlock)
 				t[i] = src[i];
 		}
 		__syncthreads();
-		if ((int)threadIdx.x < count) {
-			const double* t = reinterpret_cast<const double*>(tile) + 3 * threadIdx.x;
-			float d;
-			valid[base + threadIdx.x] = is_state_valid(m, t[0], t[1], t[2], d) ? 1 : 0;
+#pragma unroll
+		for (int k = 0; k < kCsPer; k++) {
+			const int i = k * kBlock + threadIdx.x;
+			if (i < count) {
+				const double* t = reinterpret_cast<const double*>(tile) + 3 * i;
+				valid[base + i] = is_state_valid_bit(m, t[0], t[1], t[2]) ? 1 : 0;
+			}
 		}
 		__syncthreads();
 	}
+}
+
+/// validity bitmap: one ballot per wave = two 32-bit words
+__global__ void __launch_bounds__(kBlock) k_valid_bits(const float* __restrict__ dist, int64_t cells, float minSafeRadius, uint32_t* __restrict__ bits)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool ok = i < cells && dist[i] >= minSafeRadius; // the comparison of state_validator_occupancy_map.cpp:25
+	const unsigned long long b = __ballot(ok);
+	const int lane = threadIdx.x & 63;
+	const int64_t w = (i - lane) >> 5; // first word of this wave (cells padded to a multiple of 64 by the allocation)
+	if (lane == 0)
+		bits[w] = (uint32_t)b;
+	if (lane == 32)
+		bits[w + 1] = (uint32_t)(b >> 32);
 }
 
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
@@ -91,8 +117,7 @@ __global__ void __launch_bounds__(kBlock) k_check_states_fused(MapView m, int64_
 		double x = m.lbx + (m.ubx - m.lbx) * u01(splitmix64(k));
 		double y = m.lby + (m.uby - m.lby) * u01(splitmix64(k + 1));
 		double t = m.lbt + (m.ubt - m.lbt) * u01(splitmix64(k + 2));
-		float d;
-		local += is_state_valid(m, x, y, t, d) ? 1 : 0;
+		local += is_state_valid_bit(m, x, y, t) ? 1 : 0;
 	}
 	// wave reduce (64 lanes), then one atomic per wave
 	for (int off = 32; off > 0; off >>= 1)
@@ -314,7 +339,14 @@ hipError_t launch_check_states(hipStream_t s, const MapView& m, int64_t n, const
 {
 	if (n <= 0)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_check_states, dim3(grid_for(n, kBlock, 256 * 32)), dim3(kBlock), 0, s, m, n, poses, valid, (int)((((uintptr_t)poses) & 15) == 0));
+	hipLaunchKernelGGL(k_check_states, dim3(grid_for(n, kBlock * kCsPer, 256 * 16)), dim3(kBlock), 0, s, m, n, poses, valid, (int)((((uintptr_t)poses) & 15) == 0));
+	return hipGetLastError();
+}
+hipError_t launch_valid_bits(hipStream_t s, const float* dist, int64_t cells, float minSafeRadius, uint32_t* bits)
+{
+	if (cells <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_valid_bits, dim3((unsigned)((cells + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, dist, cells, minSafeRadius, bits);
 	return hipGetLastError();
 }
 hipError_t launch_check_states_fused(hipStream_t s, const MapView& m, int64_t n, uint64_t seed, uint64_t* count)
