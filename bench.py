@@ -234,7 +234,9 @@ def main():
                           "in_search_state_checks_per_sec": state_checks * n_gpus * args.steps / elapsed},
             "kernels_ms": {"k_wavefront": wf, search_kernel: se},
             "kernel_GBs": {"k_wavefront": wf_gbs, search_kernel: se_gbs},
-            "batch_stats": {"success": n_success, "queries": B, "expansions": n_expanded, "children": n_children},
+            "batch_stats": {"success": n_success, "queries": B, "expansions": n_expanded, "children": n_children,
+                            "rs_attempts": sum(r.n_rs_attempts for r in res), "rng_draws": sum(r.n_rng_draws for r in res),
+                            "state_checks": state_checks, "path_checks": sum(r.n_path_checks for r in res)},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -1,7 +1,11 @@
 // hybrid_astar_batch -- HybridAStar::SearchPath graph search (algo/hybrid_a_star.cpp:237-257,
 // 59-173; algo/a_star.h:326-427; utils/frontier.h) for a batch of independent queries.
 //
-// One wave (64 lanes) per query, all per-query state in HBM:
+// Two kernels share the search state layout below:
+//   k_hybrid_search       one wave per query (latency: the plugin's single-query path, profiling, and the
+//                         continuation of queries the rows kernel hands over);
+//   k_hybrid_search_rows  four queries per wave on a persistent grid (throughput; pp_planner_rows.hpp).
+// k_hybrid_search -- one wave (64 lanes) per query, all per-query state in HBM:
 //   lanes      = motion primitives of the node being expanded (rollout + IsPathValid +
 //                Voronoi cost + heuristic per child), then the 48 Reeds-Shepp words of the
 //                analytic expansion;
