@@ -95,8 +95,10 @@ struct SearchArgs {
 	float rsRev, rsFwd, rsSw; // Reeds-Shepp cost weights as floats (reeds_shepp.cpp:654)
 	int maxNodes;
 	int maxPath; // PathRec entries per query
-	int suspendAfter; // rows kernel: expansions after which a query moves to the one-query-per-wave kernel (0 = never)
-	int extraSlots;   // buffer slots beyond the rows' own, taken by rows whose query was suspended
+	int suspendAfter;  // rows kernel, first pass: expansions after which a query is set aside for the second pass (0 = never)
+	int suspendAfter2; // second pass (rows kernel over the set-aside queries): expansions after which the one-query kernel takes over
+	int extraSlots;    // buffer slots beyond the rows' own, taken by rows whose query was set aside
+	int searchRows;    // rows the planner's buffers were sized for (spare slots start here)
 	size_t cells;
 	int64_t fieldElems; // floats per query in costFields (8 x 8-tiled obstacle-heuristic field)
 };
@@ -868,7 +870,7 @@ struct pp_planner {
 	bool profile = false;
 	unsigned long long* mtStates = nullptr; // [searchRows][312] mt19937_64 engine state per row (rows kernel)
 	int* nextQuery = nullptr;               // = wfError + 2: {query counter of the persistent rows kernel, spare slots handed out}
-	SuspendRec* suspended = nullptr;        // [extraSlots] queries handed over to the one-query-per-wave kernel
+	SuspendRec* suspended = nullptr;        // [2][extraSlots] queries set aside by the first / second pass of the rows kernel
 	int32_t* order = nullptr;               // [maxBatch] query indices, probable longest first (rows kernel)
 	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
 	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
@@ -1047,15 +1049,20 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		if (wanted < rows)
 			rows = wanted;
 		p->searchRows = (rows + kRowsPerWave - 1) / kRowsPerWave * kRowsPerWave;
-		// Very long queries leave the rows kernel after `suspendAfter` expansions and are finished one per wave (14 instead
-		// of ~25 us per expansion): a batch ends with its longest query (65 k expansions when a goal is unreachable for
-		// the car).  The rows kernel is the more efficient one per expansion, so only the extreme tail moves: with eight
-		// batches in flight 32768 measured best (10.2 k plans/s; 8192: 8.0 k; never: 9.8 k).
-		// PP_SEARCH_SUSPEND_AFTER=0 keeps every query in the rows kernel.
+		// A batch ends with its longest query (65 k expansions when a goal is unreachable for the car).  Queries that reach
+		// `suspendAfter` expansions are set aside by the rows kernel (open list flushed into the heap, scalars in a
+		// SuspendRec, the row goes on in a spare slot) and finished one query per wave, 14 instead of ~25 us per expansion.
+		// Only the extreme tail moves: per expansion the rows kernel is the cheaper one and the GPU is capacity-bound with
+		// eight batches in flight (measured: 32768 -> 10.2 k plans/s, 8192 -> 8.0 k, never -> 9.8 k).  Optionally a second
+		// pass of the rows kernel continues the set-aside queries up to `suspendAfter2` first (PP_SEARCH_SUSPEND_AFTER2;
+		// measured no better: 8192 / 32768 -> 7.6 k, 12288 / 32768 -> 10.1 k).  PP_SEARCH_SUSPEND_AFTER=0: no hand-over.
 		const char* cap = getenv("PP_SEARCH_SUSPEND_AFTER");
 		A.suspendAfter = p->rowsKernel ? (cap ? atoi(cap) : 32768) : 0;
+		const char* cap2 = getenv("PP_SEARCH_SUSPEND_AFTER2");
+		A.suspendAfter2 = cap2 ? atoi(cap2) : 0;
 		const char* ex = getenv("PP_SEARCH_EXTRA_SLOTS");
-		A.extraSlots = A.suspendAfter > 0 ? (ex ? atoi(ex) : (max_batch + 15) / 16) : 0; // queries that may be handed over (the rest stays)
+		A.extraSlots = A.suspendAfter > 0 ? (ex ? atoi(ex) : (max_batch + 15) / 16) : 0; // queries that may be set aside (the rest stays)
+		A.searchRows = p->searchRows;
 	}
 	hipError_t e = hipSuccess;
 	auto alloc = [&](void** ptr, size_t bytes) {
@@ -1065,10 +1072,11 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->table, tableBytes);
 	alloc((void**)&p->costFields, B * (size_t)A.fieldElems * sizeof(float));
 	alloc((void**)&p->wfWorkspace, (size_t)p->wfBytesPerSlot * p->wfSlots);
-	alloc((void**)&p->wfError, 16); // control block: {wavefront error flag, wavefront goal counter, search query counter, spare slots used}
+	alloc((void**)&p->wfError, 32); // control block: {wavefront error flag, wavefront goal counter, pass-1 query counter, pass-1 set-aside count,
+	                                // pass-2 record counter, pass-2 set-aside count}
 	// search buffers: one set per resident row (rows kernel) or per query (one-query-per-wave kernel)
 	const size_t S = p->rowsKernel ? (size_t)p->searchRows + (size_t)A.extraSlots : B;
-	alloc((void**)&p->suspended, (A.extraSlots > 0 ? (size_t)A.extraSlots : 1) * sizeof(SuspendRec));
+	alloc((void**)&p->suspended, 2 * (A.extraSlots > 0 ? (size_t)A.extraSlots : 1) * sizeof(SuspendRec));
 	alloc((void**)&p->mtStates, (p->rowsKernel ? S : 1) * Mt64::N * sizeof(unsigned long long));
 	alloc((void**)&p->nodes, S * N * sizeof(Node));
 	alloc((void**)&p->heaps, S * N * sizeof(HeapEntry));
@@ -1159,7 +1167,7 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	hipStream_t s = planner->map->ctx->stream;
 	planner->args.m = planner->map->view(); // validator tunables may have changed
 	const MapView& m = planner->args.m;
-	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 16, s)); // the step's only fill: every counter of both kernels
+	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 32, s)); // the step's only fill: every counter of every kernel
 	PP_HIP_TRY(hipEventRecord(planner->e0, s));
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
 	static const int dbgSkip = getenv("PP_DEBUG_SKIP") ? atoi(getenv("PP_DEBUG_SKIP")) : 0; // timing experiments only: 1 = no wavefront, 2 = no search
@@ -1177,14 +1185,31 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		const bool ordered = lpt && n_queries <= kOrderMax && n_queries > planner->searchRows;
 		if (ordered)
 			hipLaunchKernelGGL(k_order_queries, dim3(1), dim3(1024), 0, s, planner->args, n_queries, starts_dev, planner->costFields, planner->order);
+		int* const ctl = planner->nextQuery; // {pass-1 query counter, pass-1 set-aside count, pass-2 record counter, pass-2 set-aside count}
+		SuspendRec* const list1 = planner->suspended;
+		SuspendRec* const list2 = planner->suspended + planner->args.extraSlots;
+		const int cap1 = planner->args.suspendAfter, cap2 = planner->args.suspendAfter2;
 		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(grid), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
-			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, planner->nextQuery,
-			planner->suspended, ordered ? planner->order : nullptr);
+			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, ctl, list1,
+			ordered ? planner->order : nullptr, cap1, nullptr, nullptr, ctl + 1);
 		PP_HIP_TRY(hipGetLastError());
-		if (planner->args.extraSlots > 0) // the queries it handed over: one wave each, the block count is read on the device
+		if (cap1 > 0 && planner->args.extraSlots > 0 && cap2 <= cap1) {
+			// the set-aside queries (their number is read on the device) go straight to the one-query-per-wave kernel
 			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.extraSlots), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
-				planner->suspended, planner->nextQuery + 1, planner->mtStates);
+				list1, ctl + 1, planner->mtStates);
+		} else if (cap1 > 0 && planner->args.extraSlots > 0) {
+			// second pass of the rows kernel over the set-aside queries, then the one-query-per-wave kernel for what that
+			// pass set aside again
+			const int waves2 = (planner->args.extraSlots + kRowsPerWave - 1) / kRowsPerWave;
+			hipLaunchKernelGGL(k_hybrid_search_rows, dim3(waves2 < wavesMax ? waves2 : wavesMax), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
+				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates,
+				planner->results, ctl + 2, list2, nullptr, cap2, list1, ctl + 1, ctl + 3);
+			PP_HIP_TRY(hipGetLastError());
+			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.extraSlots), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
+				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
+				list2, ctl + 3, planner->mtStates);
+		}
 	} else if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
 			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr);

@@ -66,8 +66,14 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	const double* __restrict__ goals, const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase,
 	HeapEntry* __restrict__ heapBase, uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase,
 	PathRec* __restrict__ pathBase, unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery,
-	SuspendRec* __restrict__ suspended, const int32_t* __restrict__ order)
+	SuspendRec* __restrict__ suspended, const int32_t* __restrict__ order, int suspendAfter, const SuspendRec* __restrict__ resumeList,
+	const int* __restrict__ nResumeDev, int* __restrict__ suspendedCount)
 {
+	// Two uses.  (a) resumeList == nullptr: the rows take the batch's queries (nextQuery[0] counts them, order[] gives the
+	// hand-out order); a query that reaches `suspendAfter` expansions is written to suspended[] and its row continues in a
+	// spare slot (suspendedCount counts both).  (b) resumeList != nullptr: the rows take the records of that list
+	// (*nResumeDev of them) and continue those queries in the records' own slots; one that reaches `suspendAfter` is written
+	// to suspended[] again (for the one-query-per-wave kernel).
 	const int lane = threadIdx.x;
 	const int rl = lane & (kRowLanes - 1);
 	const int sb = (lane >> 4) * kRowSlots; // first staging slot of this row
@@ -79,7 +85,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	HeapEntry* heap = heapBase + slot * A.maxNodes;
 	uint32_t* keymap = keymapBase + slot * A.ks.size();
 	unsigned long long* mt = mtBase + slot * Mt64::N;
-	const int rowsTotal = (int)gridDim.x * kRowsPerWave;
+	const int firstSpareSlot = A.searchRows; // spare slots follow the rows' own
 	bool noSuspend = false; // no spare slot was left for this query
 
 	// staging of the children of the node being expanded (per row); kept until the next expansion so that a child popped
@@ -198,8 +204,48 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			if (rl == 0)
 				nq = atomicAdd(nextQuery, 1);
 			q = (int)row_read((uint32_t)nq, lane, 0);
-			if (q >= nQueries) {
+			const int nAvail = resumeList ? min(*nResumeDev, A.extraSlots) : nQueries;
+			if (q >= nAvail) {
 				done = true;
+			} else if (resumeList) {
+				// ---- continue a suspended query where it stopped, in the slot that holds its nodes / heap / key map / engine
+				const SuspendRec rec = resumeList[q];
+				q = rec.q;
+				slot = (size_t)rec.slot;
+				nodes = nodesBase + slot * A.maxNodes;
+				heap = heapBase + slot * A.maxNodes;
+				keymap = keymapBase + slot * A.ks.size();
+				mt = mtBase + slot * Mt64::N;
+				field = costFields + (size_t)q * A.fieldElems;
+				goal = { goals[3 * q], goals[3 * q + 1], wrap_theta(goals[3 * q + 2]) };
+				myNode = -1;
+				rsNode = -1;
+				pfNode = -1;
+				pfDead = false;
+				noSuspend = false;
+				front_clear(front);
+				frontCount = 0;
+				nSpill = 0;
+				heapSize = rec.heapSize;
+				heapTop.ckey = ~0ull;
+				heapTop.nseq = ~0u;
+				heapTop.node = 0;
+				if (heapSize > 0)
+					heapTop = heap[0]; // the whole open list was flushed into the heap at suspension
+				nNodes = rec.nNodes;
+				seq = rec.seq;
+				nExpanded = rec.nExpanded;
+				nRngDraws = rec.nRngDraws;
+				nRsAttempts = rec.nRsAttempts;
+				nRsLog = rec.nRsLog;
+				mtIdx = rec.mtIdx;
+				laneStateChecks = rl == 0 ? rec.stateChecks : 0; // the totals so far ride in the row's first lane
+				lanePathChecks = rl == 0 ? rec.pathChecks : 0;
+				rsStateChecks = rsPathChecks = 0;
+				status = -1;
+				solutionNode = -1;
+				solutionCost = __builtin_huge_val();
+				act = true;
 			} else {
 				if (order)
 					q = order[q]; // probable longest first (k_order_queries)
@@ -291,12 +337,13 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 		}
 		if (nSpill > 0)
 			flush_spills();
-		if (A.suspendAfter > 0 && nExpanded >= A.suspendAfter && !noSuspend) {
-			// ---- hand the query over: its open list goes entirely into the heap, the scalars into a SuspendRec; the row
-			// continues with the next query in a spare slot (nextQuery[1] counts the spare slots handed out)
+		if (suspendAfter > 0 && nExpanded >= suspendAfter && !noSuspend) {
+			// ---- hand the query over: its open list goes entirely into the heap, the scalars into a SuspendRec.  A row
+			// working on the batch continues with the next query in a spare slot (one per record); a row working on a
+			// resume list simply takes the next record (and that record's slot).
 			int ns = 0;
 			if (rl == 0)
-				ns = atomicAdd(nextQuery + 1, 1);
+				ns = atomicAdd(suspendedCount, 1);
 			ns = (int)row_read((uint32_t)ns, lane, 0);
 			if (ns >= A.extraSlots) {
 				noSuspend = true;
@@ -329,11 +376,13 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 					r.pathChecks = pc;
 					suspended[ns] = r;
 				}
-				slot = (size_t)rowsTotal + (size_t)ns;
-				nodes = nodesBase + slot * A.maxNodes;
-				heap = heapBase + slot * A.maxNodes;
-				keymap = keymapBase + slot * A.ks.size();
-				mt = mtBase + slot * Mt64::N;
+				if (!resumeList) {
+					slot = (size_t)firstSpareSlot + (size_t)ns;
+					nodes = nodesBase + slot * A.maxNodes;
+					heap = heapBase + slot * A.maxNodes;
+					keymap = keymapBase + slot * A.ks.size();
+					mt = mtBase + slot * Mt64::N;
+				}
 				wave_vmem_sync();
 				act = false;
 				continue;

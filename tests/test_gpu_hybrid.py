@@ -207,11 +207,13 @@ def test_config5_4096_map_queries():
 
 
 def test_long_queries_are_handed_over_to_the_one_query_kernel(monkeypatch):
-    """Rows kernel with hand-over after 40 expansions: most queries are suspended (open list flushed into the heap,
-    scalars in a SuspendRec) and finished by the one-query-per-wave kernel in the same slot; only 6 spare slots, so the
-    others stay in the rows kernel.  Expansion logs, counters and paths must not notice."""
+    """Rows kernel in three stages: queries beyond 40 expansions are set aside (open list flushed into the heap, scalars
+    in a SuspendRec) and continued by a second pass of the rows kernel in the same slot; beyond 150 expansions the
+    one-query-per-wave kernel finishes them.  Only 6 spare slots first, so most long queries stay in the first pass.
+    Expansion logs, counters and paths must not notice."""
     monkeypatch.setenv("PP_SEARCH_ROWS", "1")
-    monkeypatch.setenv("PP_SEARCH_SUSPEND_AFTER", "40")
+    monkeypatch.setenv("PP_SEARCH_SUSPEND_AFTER", "40")    # first pass of the rows kernel
+    monkeypatch.setenv("PP_SEARCH_SUSPEND_AFTER2", "150")  # second pass; beyond: one query per wave
     monkeypatch.setenv("PP_SEARCH_EXTRA_SLOTS", "6")
     w, ms, val, ctx = make_pair(256, 6, 3)
     rng = np.random.RandomState(41)
@@ -220,7 +222,7 @@ def test_long_queries_are_handed_over_to_the_one_query_kernel(monkeypatch):
     goals = valid_random_poses(rng, w, n)
     seeds = np.arange(n, dtype=np.uint64) + 500
     planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=8)
-    assert sum(1 for r in res if r.n_expanded > 40) > 10
+    assert sum(1 for r in res if r.n_expanded > 40) > 10 and sum(1 for r in res if r.n_expanded > 150) > 3
     assert compare(planner, res, h, starts, goals, seeds) >= n // 2
     monkeypatch.setenv("PP_SEARCH_EXTRA_SLOTS", "64")  # every long query handed over
     planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=8)
