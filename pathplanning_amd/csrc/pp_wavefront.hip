@@ -494,12 +494,16 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 	NbhdRaw raw[4];
 #pragma unroll
 	for (int u = 0; u < 4; u++) {
+		if ((uint32_t)(u * WF_T) >= w)
+			break; // (uniform) nothing left for any thread
 		const uint32_t i = (uint32_t)(tid + u * WF_T);
 		k[u] = i < w ? skey[SK((int)i)] : ~0ull;
 	}
 	__syncthreads();
 #pragma unroll
 	for (int u = 0; u < 4; u++) {
+		if ((uint32_t)(u * WF_T) >= w)
+			break; // (uniform) nothing left for any thread
 		const uint32_t i = (uint32_t)(tid + u * WF_T);
 		if (i < w) {
 			const uint32_t cell = unpack_cell((uint32_t)k[u] & cellMask, cb);
@@ -508,6 +512,8 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 	}
 #pragma unroll
 	for (int u = 0; u < 4; u++) {
+		if ((uint32_t)(u * WF_T) >= w)
+			break; // (uniform) nothing left for any thread
 		const uint32_t i = (uint32_t)(tid + u * WF_T);
 		if (i < w) {
 			const uint32_t bkt = (uint32_t)(k[u] >> shiftD) >> shift;
@@ -531,6 +537,8 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 	bool multi = false;
 #pragma unroll
 	for (int u = 0; u < 4; u++) {
+		if ((uint32_t)(u * WF_T) >= w)
+			break; // (uniform) nothing left for any thread
 		const uint32_t i = (uint32_t)(tid + u * WF_T);
 		if (i < w) {
 			const uint32_t bkt = meta[u] & (WF_NB - 1), arr = meta[u] >> 11;
@@ -544,6 +552,8 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 	reinterpret_cast<uint4*>(hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
 	for (int u = 0; u < 4; u++) {
+		if ((uint32_t)(u * WF_T) >= w)
+			break; // (uniform) nothing left for any thread
 		const uint32_t i = (uint32_t)(tid + u * WF_T);
 		if (i < w) {
 			const uint32_t st = meta[u] & 0xFFFu, size = meta[u] >> 12;
@@ -557,6 +567,8 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 	lds_barrier();
 #pragma unroll
 	for (int u = 0; u < 4; u++) {
+		if ((uint32_t)(u * WF_T) >= w)
+			break; // (uniform) nothing left for any thread
 		const uint32_t i = (uint32_t)(tid + u * WF_T);
 		if (i < w) {
 			if (multi) // a lane whose buckets are all singletons already sits at its rank
@@ -722,6 +734,13 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 #pragma unroll
 				for (int u = 0; u < 8; u++) {
 					const uint32_t i = (uint32_t)(u * WF_T + tid);
+					if ((uint32_t)(u * WF_T) >= n) { // (uniform) the list ends before this row of entries
+						e[u] = ~0ull;
+						bw[u] = br[u] = 0ull;
+						if (lane == 0)
+							s_wcnt[u * WF_W + wave] = 0u;
+						continue;
+					}
 					e[u] = i < n ? lent[i] : ~0ull;
 					const bool inW = i < n && (uint32_t)(e[u] >> 32) < hiBits;
 					bw[u] = __ballot(inW);
@@ -738,6 +757,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				b = total & 0xFFFFu;
 #pragma unroll
 				for (int u = 0; u < 8; u++) {
+					if ((uint32_t)(u * WF_T) >= n)
+						break; // (uniform)
 					const uint32_t i = (uint32_t)(u * WF_T + tid);
 					const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)excl, u * WF_W + wave);
 					const uint32_t c = (uint32_t)(e[u] >> 32), cell = (uint32_t)e[u];
