@@ -491,7 +491,8 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 	const int shift = bitsRange > 11 ? bitsRange - 11 : 0; // (cost - L) >> shift < WF_NB
 	uint64_t k[4];
 	uint32_t meta[4];
-	NbhdRaw raw[4];
+	constexpr int kAhead = 2; // elements per thread whose loads fly under the sort (more would spill the loaded words)
+	NbhdRaw raw[kAhead];
 #pragma unroll
 	for (int u = 0; u < 4; u++) {
 		if ((uint32_t)(u * WF_T) >= w)
@@ -501,7 +502,7 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 	}
 	__syncthreads();
 #pragma unroll
-	for (int u = 0; u < 4; u++) {
+	for (int u = 0; u < kAhead; u++) {
 		if ((uint32_t)(u * WF_T) >= w)
 			break; // (uniform) nothing left for any thread
 		const uint32_t i = (uint32_t)(tid + u * WF_T);
@@ -574,7 +575,12 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 			if (multi) // a lane whose buckets are all singletons already sits at its rank
 				skey[SK((int)meta[u])] = k[u];
 			Row3 up, mid, dn;
-			nbhd_finish(raw[u], up, mid, dn); // first use of the loaded words: the wait for them sits here
+			if (u < kAhead) {
+				nbhd_finish(raw[u], up, mid, dn); // first use of the loaded words: the wait for them sits here
+			} else { // windows beyond kAhead * WF_T cells: the rest is fetched now
+				const uint32_t cell = unpack_cell((uint32_t)k[u] & cellMask, cb);
+				load_state_nbhd(state, tpr, (int)(cell >> 16), (int)(cell & 0xFFFFu), up, mid, dn);
+			}
 			smask[meta[u]] = (uint8_t)candidate_mask(up, mid, dn);
 		}
 	}
