@@ -35,7 +35,7 @@ CHILD_BYTES = 143.0                # per expansion child
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=8, help="untimed steps; the default touches every batch lane once")
     ap.add_argument("--batch", type=int, default=4096, help="queries per GPU per step")
     ap.add_argument("--cells", type=int, default=1024)

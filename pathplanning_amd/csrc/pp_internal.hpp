@@ -68,13 +68,16 @@ int64_t wavefront_workspace_bytes(int rows, int cols);
 /// workgroups of the wavefront kernel that are resident at once on the current device (occupancy API x CUs)
 int wavefront_resident_blocks();
 /// Runs nGoals wavefronts; goalCells[g] = row*cols+col or -1 (goal outside the map -> field stays +inf).
+/// orderStartsDev / orderOutDev / doneCounterDev / orderKeysDev[nGoals] (optional, nGoals <= 4096): the last workgroup writes the goal indices ordered by
+/// decreasing field value at the start pose (x, y, theta triples) -- the planner's hand-out order; *doneCounterDev must be 0.
 /// goalPosesDev (optional): (x, y, theta) triples from which the kernel derives the goal cells itself (goalCellsDev unused);
 /// countersZeroed: the caller has already cleared errorFlagDev[0..1] on the stream.
 /// tiledOut: costDev is [nGoals][field_tiled_elems] in the 8 x 8-tiled layout of pp_device.hpp (what the search kernel
 /// reads); otherwise [nGoals][rows*cols] row-major (the public a8 entry points).
 hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
 	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev = nullptr, bool tiledOut = false,
-	const double* goalPosesDev = nullptr, bool countersZeroed = false);
+	const double* goalPosesDev = nullptr, bool countersZeroed = false, const double* orderStartsDev = nullptr, int32_t* orderOutDev = nullptr,
+	int* doneCounterDev = nullptr, float* orderKeysDev = nullptr);
 
 } // namespace pph
 

@@ -872,6 +872,7 @@ struct pp_planner {
 	int* nextQuery = nullptr;               // = wfError + 2: {query counter of the persistent rows kernel, spare slots handed out}
 	SuspendRec* suspended = nullptr;        // [2][extraSlots] queries set aside by the first / second pass of the rows kernel
 	int32_t* order = nullptr;               // [maxBatch] query indices, probable longest first (rows kernel)
+	float* orderKeys = nullptr;             // [maxBatch] field value at each query's start pose (the sort key)
 	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
 	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
 	bool rowsKernel = false;                // four-queries-per-wave kernel (throughput) vs one query per wave (latency)
@@ -893,7 +894,7 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
-	void* ptrs[] = { p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -1083,6 +1084,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->keymaps, S * A.ks.size() * 4);
 	alloc((void**)&p->expanded, B * N * 4);
 	alloc((void**)&p->order, B * 4);
+	alloc((void**)&p->orderKeys, B * 4);
 	alloc((void**)&p->paths, B * (size_t)A.maxPath * sizeof(PathRec));
 	alloc((void**)&p->rsLogs, B * kRsLogCap * sizeof(RsLogEntry));
 	alloc((void**)&p->results, B * sizeof(DevResult));
@@ -1169,11 +1171,15 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	const MapView& m = planner->args.m;
 	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 32, s)); // the step's only fill: every counter of every kernel
 	PP_HIP_TRY(hipEventRecord(planner->e0, s));
+	// the rows kernel hands the queries out longest-first (order written by the wavefront kernel's last workgroup)
+	static const bool lpt = !(getenv("PP_SEARCH_ORDER") && getenv("PP_SEARCH_ORDER")[0] == '0');
+	const bool ordered = planner->rowsKernel && lpt && n_queries <= 4096 && n_queries > planner->searchRows;
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
 	static const int dbgSkip = getenv("PP_DEBUG_SKIP") ? atoi(getenv("PP_DEBUG_SKIP")) : 0; // timing experiments only: 1 = no wavefront, 2 = no search
 	if (dbgSkip != 1)
 	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
-		planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true));
+		planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true, ordered ? starts_dev : nullptr, ordered ? planner->order : nullptr,
+		planner->wfError + 6, planner->orderKeys));
 	PP_HIP_TRY(hipEventRecord(planner->e1, s));
 	if (dbgSkip == 2) {
 	} else if (planner->rowsKernel) {
@@ -1181,10 +1187,6 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		const int wavesWanted = (n_queries + kRowsPerWave - 1) / kRowsPerWave;
 		const int wavesMax = planner->searchRows / kRowsPerWave;
 		const int grid = wavesWanted < wavesMax ? wavesWanted : wavesMax;
-		static const bool lpt = !(getenv("PP_SEARCH_ORDER") && getenv("PP_SEARCH_ORDER")[0] == '0');
-		const bool ordered = lpt && n_queries <= kOrderMax && n_queries > planner->searchRows;
-		if (ordered)
-			hipLaunchKernelGGL(k_order_queries, dim3(1), dim3(1024), 0, s, planner->args, n_queries, starts_dev, planner->costFields, planner->order);
 		int* const ctl = planner->nextQuery; // {pass-1 query counter, pass-1 set-aside count, pass-2 record counter, pass-2 set-aside count}
 		SuspendRec* const list1 = planner->suspended;
 		SuspendRec* const list2 = planner->suspended + planner->args.extraSlots;

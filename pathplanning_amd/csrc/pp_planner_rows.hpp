@@ -19,48 +19,6 @@
 // oracle (tests/test_gpu_hybrid.py checks the expanded sequence).
 #pragma once
 
-// ------------------------------------------------------------------------------------------- query ordering --
-/// The rows take queries from a counter; handing out the probably longest first (largest obstacle-heuristic value at the
-/// start pose; unreachable = +inf first) packs the rows better: a wave costs the same with one active row as with four.
-/// One workgroup, bitonic sort of (key, index) pairs in LDS; n <= kOrderMax.
-constexpr int kOrderMax = 8192;
-__global__ void __launch_bounds__(1024) k_order_queries(SearchArgs A, int n, const double* __restrict__ starts, const float* __restrict__ costFields, int32_t* __restrict__ order)
-{
-	__shared__ unsigned long long s[kOrderMax];
-	int P = 1;
-	while (P < n)
-		P <<= 1;
-	for (int i = threadIdx.x; i < P; i += blockDim.x) {
-		unsigned long long v = 0ull; // padding sorts last (descending order)
-		if (i < n) {
-			int row, col;
-			world_to_cell(A.m, starts[3 * i], starts[3 * i + 1], row, col);
-			float c = __builtin_huge_valf();
-			if (inside_map(A.m, row, col))
-				c = (costFields + (size_t)i * A.fieldElems)[field_tiled_index(A.m.cols, row, col)];
-			// non-negative floats order like their bit patterns; +1 keeps real entries above the padding
-			v = ((unsigned long long)(__float_as_uint(c) + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-		}
-		s[i] = v;
-	}
-	__syncthreads();
-	for (int kk = 2; kk <= P; kk <<= 1)
-		for (int j = kk >> 1; j > 0; j >>= 1) {
-			for (int t = threadIdx.x; t < P / 2; t += blockDim.x) {
-				const int i1 = ((t / j) * 2 * j) + (t % j), i2 = i1 + j;
-				const bool desc = (i1 & kk) == 0; // descending overall
-				const unsigned long long a = s[i1], b = s[i2];
-				if ((a < b) == desc) {
-					s[i1] = b;
-					s[i2] = a;
-				}
-			}
-			__syncthreads();
-		}
-	for (int i = threadIdx.x; i < n; i += blockDim.x)
-		order[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)s[i]);
-}
-
 // --------------------------------------------------------------------------------------------------- kernel --
 __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_rows(SearchArgs A, int nQueries, const double* __restrict__ starts,
 	const double* __restrict__ goals, const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase,
@@ -248,7 +206,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				act = true;
 			} else {
 				if (order)
-					q = order[q]; // probable longest first (k_order_queries)
+					q = order[q]; // probable longest first (written by the wavefront kernel's last workgroup)
 				field = costFields + (size_t)q * A.fieldElems;
 				{ // the slot's key map still holds the previous query of this row
 					const size_t n = A.ks.size(), n4 = n / 4;

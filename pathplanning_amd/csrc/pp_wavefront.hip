@@ -593,7 +593,7 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 template <bool kProfile>
 __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapView m, int nGoals, const int32_t* __restrict__ goalCells, float* __restrict__ costOut,
 	void* workspace, int64_t bytesPerSlot, uint32_t fcap, uint32_t gcap, int32_t* errorFlag, unsigned long long* __restrict__ prof, int* __restrict__ goalCounter,
-	int tiledOut, const double* __restrict__ goalPoses)
+	int tiledOut, const double* __restrict__ goalPoses, const double* __restrict__ orderStarts, int32_t* __restrict__ orderOut, int* __restrict__ doneCounter, float* __restrict__ orderKeys)
 {
 	unsigned long long ph[WP_COUNT];
 	unsigned long long tl = 0;
@@ -1198,11 +1198,62 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		if (overflow && tid == 0)
 			*errorFlag = 1; // open list / round count beyond the workspace encoding
 		__syncthreads();
+		if (orderOut && tid == 0) {
+			// hand-out key of this query: the field value at its start pose, published with a device-scope store (the
+			// workgroup that sorts the keys may sit on another XCD, whose L2 does not see this one's plain stores)
+			int row, col;
+			world_to_cell(m, orderStarts[3 * g], orderStarts[3 * g + 1], row, col);
+			float c = __builtin_huge_valf();
+			if (inside_map(m, row, col))
+				c = cost[tiledOut ? field_tiled_index(cols, row, col) : (size_t)row * cols + col];
+			__hip_atomic_store(orderKeys + g, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
 		if (kProfile && tid == 0)
 			for (int i = 0; i < WP_COUNT; i++)
 				prof[(size_t)g * WP_COUNT + i] = ph[i];
 	}
 #undef WF_STAMP
+	// ---- optional epilogue for the planner: the LAST workgroup to run out of goals orders the queries by decreasing
+	// field value at their start pose (probable longest search first; +inf = unreachable first) for the search kernel's
+	// hand-out -- no extra launch that would queue behind persistent grids.  nGoals <= WF_LCAP.
+	if (orderOut) {
+		__syncthreads();
+		if (tid == 0) {
+			__builtin_amdgcn_s_waitcnt(0); // this workgroup's key stores have reached the coherence point
+			s_goal = __hip_atomic_fetch_add(doneCounter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1 ? 1 : 0;
+		}
+		__syncthreads();
+		if (s_goal) {
+			int P = 1;
+			while (P < nGoals)
+				P <<= 1;
+			for (int i = tid; i < P; i += WF_T) {
+				unsigned long long v = 0ull; // padding sorts last (descending order)
+				if (i < nGoals) {
+					const float c = __hip_atomic_load(orderKeys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					// non-negative floats order like their bit patterns; +1 keeps real entries above the padding
+					v = ((unsigned long long)(__float_as_uint(c) + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+				}
+				skey[i] = v;
+			}
+			__syncthreads();
+			for (int kk = 2; kk <= P; kk <<= 1)
+				for (int j = kk >> 1, lj = 31 - __clz(kk >> 1); j > 0; j >>= 1, lj--) {
+					for (int t = tid; t < P / 2; t += WF_T) {
+						const int i1 = ((t >> lj) << (lj + 1)) | (t & (j - 1)), i2 = i1 + j;
+						const bool desc = (i1 & kk) == 0;
+						const unsigned long long a = skey[i1], b = skey[i2];
+						if ((a < b) == desc) {
+							skey[i1] = b;
+							skey[i2] = a;
+						}
+					}
+					__syncthreads();
+				}
+			for (int i = tid; i < nGoals; i += WF_T)
+				orderOut[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)skey[i]);
+		}
+	}
 }
 
 } // namespace
@@ -1240,8 +1291,11 @@ int wavefront_resident_blocks()
 }
 
 hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
-	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev, bool tiledOut, const double* goalPosesDev, bool countersZeroed)
+	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev, bool tiledOut, const double* goalPosesDev, bool countersZeroed,
+	const double* orderStartsDev, int32_t* orderOutDev, int* doneCounterDev, float* orderKeysDev)
 {
+	if (nGoals > WF_LCAP)
+		orderOutDev = nullptr; // the epilogue sorts in the LDS sort buffer
 	if (nGoals <= 0)
 		return hipSuccess;
 	uint32_t fcap, gcap;
@@ -1255,10 +1309,10 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 	}
 	if (profDev)
 		hipLaunchKernelGGL(k_wavefront<true>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev);
+			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev);
 	else
 		hipLaunchKernelGGL(k_wavefront<false>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev);
+			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev);
 	return hipGetLastError();
 }
 
