@@ -99,6 +99,7 @@ struct SearchArgs {
 	int suspendAfter2; // second pass (rows kernel over the set-aside queries): expansions after which the one-query kernel takes over
 	int extraSlots;    // buffer slots beyond the rows' own, taken by rows whose query was set aside
 	int searchRows;    // rows the planner's buffers were sized for (spare slots start here)
+	int listCap;       // capacity of each SuspendRec list: one record per spare slot + one per row
 	size_t cells;
 	int64_t fieldElems; // floats per query in costFields (8 x 8-tiled obstacle-heuristic field)
 };
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 {
 	// Two uses: (a) one block per query of the batch, buffers indexed by the query (resume == nullptr);
 	// (b) continuation of the queries the rows kernel suspended: one block per SuspendRec, buffers indexed by its slot.
-	if (resume ? ((int)blockIdx.x >= *nResume || (int)blockIdx.x >= A.extraSlots) : (int)blockIdx.x >= nQueries)
+	if (resume ? ((int)blockIdx.x >= *nResume || (int)blockIdx.x >= A.listCap) : (int)blockIdx.x >= nQueries)
 		return;
 	const SuspendRec rec = resume ? resume[blockIdx.x] : SuspendRec {};
 	const int q = resume ? rec.q : (int)blockIdx.x;
@@ -876,6 +877,7 @@ struct pp_planner {
 	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
 	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
 	bool rowsKernel = false;                // four-queries-per-wave kernel (throughput) vs one query per wave (latency)
+	int compactBelow = 0;                   // first pass: a wave with an empty queue and <= this many busy rows re-queues them
 	PathRec* paths = nullptr;               // [maxBatch][maxPath] solution paths, goal first
 	int maxPath = 0;
 	double *dStarts = nullptr, *dGoals = nullptr;
@@ -1064,6 +1066,14 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		const char* ex = getenv("PP_SEARCH_EXTRA_SLOTS");
 		A.extraSlots = A.suspendAfter > 0 ? (ex ? atoi(ex) : (max_batch + 15) / 16) : 0; // queries that may be set aside (the rest stays)
 		A.searchRows = p->searchRows;
+		A.listCap = A.extraSlots + p->searchRows;
+		// compaction (pp_planner_rows.hpp): waves whose queue is empty and that have at most this many busy rows re-queue
+		// their queries for a second pass that packs them four per wave.  Off by default: it issues fewer instructions
+		// (a wave costs the same with one busy row as with four) but the passes of one batch run one after the other, and
+		// with eight batches in flight the longer per-batch latency costs more than the saved issue slots
+		// (measured: 8.1 k plans/s with PP_SEARCH_COMPACT=2 against 10.9 k without).
+		const char* cpt = getenv("PP_SEARCH_COMPACT");
+		p->compactBelow = p->rowsKernel && cpt ? atoi(cpt) : 0;
 	}
 	hipError_t e = hipSuccess;
 	auto alloc = [&](void** ptr, size_t bytes) {
@@ -1077,7 +1087,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	                                // pass-2 record counter, pass-2 set-aside count}
 	// search buffers: one set per resident row (rows kernel) or per query (one-query-per-wave kernel)
 	const size_t S = p->rowsKernel ? (size_t)p->searchRows + (size_t)A.extraSlots : B;
-	alloc((void**)&p->suspended, 2 * (A.extraSlots > 0 ? (size_t)A.extraSlots : 1) * sizeof(SuspendRec));
+	alloc((void**)&p->suspended, 2 * (size_t)(A.listCap > 0 ? A.listCap : 1) * sizeof(SuspendRec));
 	alloc((void**)&p->mtStates, (p->rowsKernel ? S : 1) * Mt64::N * sizeof(unsigned long long));
 	alloc((void**)&p->nodes, S * N * sizeof(Node));
 	alloc((void**)&p->heaps, S * N * sizeof(HeapEntry));
@@ -1187,31 +1197,29 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		const int wavesWanted = (n_queries + kRowsPerWave - 1) / kRowsPerWave;
 		const int wavesMax = planner->searchRows / kRowsPerWave;
 		const int grid = wavesWanted < wavesMax ? wavesWanted : wavesMax;
-		int* const ctl = planner->nextQuery; // {pass-1 query counter, pass-1 set-aside count, pass-2 record counter, pass-2 set-aside count}
+		int* const ctl = planner->nextQuery; // {pass-1 query counter, list-1 count, pass-2 record counter, list-2 count, (wavefront), spare slots}
+		int* const spare = planner->wfError + 7;
 		SuspendRec* const list1 = planner->suspended;
-		SuspendRec* const list2 = planner->suspended + planner->args.extraSlots;
-		const int cap1 = planner->args.suspendAfter, cap2 = planner->args.suspendAfter2;
+		SuspendRec* const list2 = planner->suspended + planner->args.listCap;
+		const int cap1 = planner->args.suspendAfter, cap2 = planner->args.suspendAfter2, cpt = planner->compactBelow;
 		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(grid), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
 			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, ctl, list1,
-			ordered ? planner->order : nullptr, cap1, nullptr, nullptr, ctl + 1);
+			ordered ? planner->order : nullptr, cap1, nullptr, nullptr, ctl + 1, spare, cpt);
 		PP_HIP_TRY(hipGetLastError());
-		if (cap1 > 0 && planner->args.extraSlots > 0 && cap2 <= cap1) {
-			// the set-aside queries (their number is read on the device) go straight to the one-query-per-wave kernel
-			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.extraSlots), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
-				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
-				list1, ctl + 1, planner->mtStates);
-		} else if (cap1 > 0 && planner->args.extraSlots > 0) {
-			// second pass of the rows kernel over the set-aside queries, then the one-query-per-wave kernel for what that
-			// pass set aside again
-			const int waves2 = (planner->args.extraSlots + kRowsPerWave - 1) / kRowsPerWave;
+		const bool secondPass = cpt > 0 || (cap1 > 0 && cap2 > cap1);
+		if (secondPass) {
+			// second pass of the rows kernel over list 1 (its length is read on the device); it ends waves with a single
+			// busy row, and the one-query-per-wave kernel finishes those
+			const int waves2 = (planner->args.listCap + kRowsPerWave - 1) / kRowsPerWave;
 			hipLaunchKernelGGL(k_hybrid_search_rows, dim3(waves2 < wavesMax ? waves2 : wavesMax), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates,
-				planner->results, ctl + 2, list2, nullptr, cap2, list1, ctl + 1, ctl + 3);
+				planner->results, ctl + 2, list2, nullptr, cap2 > cap1 ? cap2 : 0, list1, ctl + 1, ctl + 3, spare, cpt > 0 ? 1 : 0);
 			PP_HIP_TRY(hipGetLastError());
-			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.extraSlots), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
-				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
-				list2, ctl + 3, planner->mtStates);
 		}
+		if (secondPass || cap1 > 0) // whatever is still set aside: one wave per query (the block count is read on the device)
+			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.listCap), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
+				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
+				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates);
 	} else if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
 			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr);

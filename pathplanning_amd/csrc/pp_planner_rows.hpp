@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	HeapEntry* __restrict__ heapBase, uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase,
 	PathRec* __restrict__ pathBase, unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery,
 	SuspendRec* __restrict__ suspended, const int32_t* __restrict__ order, int suspendAfter, const SuspendRec* __restrict__ resumeList,
-	const int* __restrict__ nResumeDev, int* __restrict__ suspendedCount)
+	const int* __restrict__ nResumeDev, int* __restrict__ suspendedCount, int* __restrict__ spareCount, int compactBelow)
 {
 	// Two uses.  (a) resumeList == nullptr: the rows take the batch's queries (nextQuery[0] counts them, order[] gives the
 	// hand-out order); a query that reaches `suspendAfter` expansions is written to suspended[] and its row continues in a
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			if (rl == 0)
 				nq = atomicAdd(nextQuery, 1);
 			q = (int)row_read((uint32_t)nq, lane, 0);
-			const int nAvail = resumeList ? min(*nResumeDev, A.extraSlots) : nQueries;
+			const int nAvail = resumeList ? min(*nResumeDev, A.listCap) : nQueries;
 			if (q >= nAvail) {
 				done = true;
 			} else if (resumeList) {
@@ -283,8 +283,11 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				act = true;
 			}
 		}
-		if (!__ballot(act))
+		const unsigned long long actMask = __ballot(act);
+		if (!actMask)
 			break; // every row has run out of queries
+		// compaction trigger (all lanes vote): some row found the queue empty and few rows of the wave are still busy
+		const bool compact = compactBelow > 0 && __ballot(done) != 0ull && __popcll(actMask) <= compactBelow * kRowLanes;
 		if (!act)
 			continue;
 
@@ -295,17 +298,29 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 		}
 		if (nSpill > 0)
 			flush_spills();
-		if (suspendAfter > 0 && nExpanded >= suspendAfter && !noSuspend) {
-			// ---- hand the query over: its open list goes entirely into the heap, the scalars into a SuspendRec.  A row
-			// working on the batch continues with the next query in a spare slot (one per record); a row working on a
-			// resume list simply takes the next record (and that record's slot).
-			int ns = 0;
-			if (rl == 0)
-				ns = atomicAdd(suspendedCount, 1);
-			ns = (int)row_read((uint32_t)ns, lane, 0);
-			if (ns >= A.extraSlots) {
+		// ---- setting a query aside: its open list goes entirely into the heap, the scalars into a SuspendRec of the next
+		// stage's list.  Two triggers: (a) the query reached `suspendAfter` expansions -- a row working on the batch then
+		// continues with the next query in a spare slot, a row working on a resume list takes the next record (and its
+		// slot); (b) compaction: the queue is empty and at most `compactBelow` rows of this wave are still busy -- a wave
+		// costs the same with one busy row as with four, so the leftovers of all such waves are re-packed four per wave
+		// by the next stage and this wave ends.
+		const bool capHit = suspendAfter > 0 && nExpanded >= suspendAfter && !noSuspend;
+		if (capHit || compact) {
+			bool ok = true;
+			int sp = 0;
+			if (!compact && !resumeList) { // the row goes on: it needs a spare slot
+				if (rl == 0)
+					sp = atomicAdd(spareCount, 1);
+				sp = (int)row_read((uint32_t)sp, lane, 0);
+				ok = sp < A.extraSlots;
+			}
+			if (!ok) {
 				noSuspend = true;
 			} else {
+				int ns = 0;
+				if (rl == 0)
+					ns = atomicAdd(suspendedCount, 1);
+				ns = (int)row_read((uint32_t)ns, lane, 0); // < listCap: at most one record per row and spare slot
 				if (rl < frontCount) {
 					HeapEntry e;
 					e.ckey = front.ckey;
@@ -318,7 +333,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				if (nSpill > 0)
 					flush_spills();
 				const long long sc = row_sum_i64(laneStateChecks, lane) + rsStateChecks, pc = row_sum_i64(lanePathChecks, lane) + rsPathChecks;
-				if (rl == 0) {
+				if (rl == 0 && ns < A.listCap) {
 					SuspendRec r;
 					r.q = q;
 					r.slot = (int32_t)slot;
@@ -334,8 +349,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 					r.pathChecks = pc;
 					suspended[ns] = r;
 				}
-				if (!resumeList) {
-					slot = (size_t)firstSpareSlot + (size_t)ns;
+				if (compact) {
+					done = true; // nothing left to fetch: the wave ends once its rows have stored their records
+				} else if (!resumeList) {
+					slot = (size_t)firstSpareSlot + (size_t)sp;
 					nodes = nodesBase + slot * A.maxNodes;
 					heap = heapBase + slot * A.maxNodes;
 					keymap = keymapBase + slot * A.ks.size();

@@ -227,6 +227,12 @@ def test_long_queries_are_handed_over_to_the_one_query_kernel(monkeypatch):
     monkeypatch.setenv("PP_SEARCH_EXTRA_SLOTS", "64")  # every long query handed over
     planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=8)
     assert compare(planner, res, h, starts, goals, seeds) >= n // 2
+    # compaction: waves with an empty queue and <= 2 busy rows re-queue their queries for the second pass
+    monkeypatch.setenv("PP_SEARCH_COMPACT", "2")
+    monkeypatch.setenv("PP_SEARCH_SUSPEND_AFTER", "100000")
+    monkeypatch.setenv("PP_SEARCH_SUSPEND_AFTER2", "0")
+    planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=8)
+    assert compare(planner, res, h, starts, goals, seeds) >= n // 2
 
 
 def test_handles_may_be_destroyed_in_any_order():
