@@ -94,22 +94,6 @@ inline uint32_t next_pow2(uint32_t v)
 	return p;
 }
 
-// ---- wave-level ballot / prefix compaction: the lanes of a wave that want a slot reserve a contiguous range
-// with ONE atomic on the shared counter (a per-lane atomicAdd on one LDS word serialises ~2.4k times per round).
-__device__ __forceinline__ uint32_t wave_alloc(uint32_t* counter, bool want)
-{
-	const unsigned long long mask = __ballot(want);
-	if (mask == 0ull)
-		return 0u;
-	const int lane = threadIdx.x & 63;
-	const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-	uint32_t base = 0;
-	if (lane == __ffsll((long long)mask) - 1)
-		base = atomicAdd(counter, (uint32_t)__popcll(mask));
-	base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)mask) - 1);
-	return base + prefix;
-}
-
 /// LDS position of sort element i: one slot of skew per 32 elements, so that power-of-two strides (the only
 /// ones a bitonic network uses) spread over all banks instead of hitting 2-4 of them.
 __device__ __forceinline__ int SK(int i) { return i + (i >> 5); }
@@ -180,85 +164,6 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* keys, uint32_t* vals, int
 			}
 		}
 	}
-}
-
-// ---- packed-key sort in LDS, several strides per pass.  A thread takes 2^S elements spaced by the smallest
-// stride of the pass and applies S consecutive strides of the bitonic network in registers: one LDS round trip
-// per pass instead of one per stride (the sort is LDS-latency bound: ~600 cycles per round trip at 8 waves).
-template <int S>
-__device__ __forceinline__ void bitonic_pass(uint64_t* keys, int g, int ljmin, int k)
-{
-	constexpr int N = 1 << S;
-	const int jmin = 1 << ljmin;
-	const int base = ((g >> ljmin) << (ljmin + S)) | (g & (jmin - 1));
-	const bool up = (base & k) == 0; // all N elements lie in one 2*jmax block, so they share the direction
-	uint64_t v[N];
-#pragma unroll
-	for (int e = 0; e < N; e++)
-		v[e] = keys[SK(base + e * jmin)];
-#pragma unroll
-	for (int st = S - 1; st >= 0; st--) { // stride jmin << st
-#pragma unroll
-		for (int e = 0; e < N; e++) {
-			if (!(e & (1 << st))) {
-				const int f = e | (1 << st);
-				const uint64_t a = v[e], b = v[f];
-				const bool sw = (a > b) == up;
-				v[e] = sw ? b : a;
-				v[f] = sw ? a : b;
-			}
-		}
-	}
-#pragma unroll
-	for (int e = 0; e < N; e++)
-		keys[SK(base + e * jmin)] = v[e];
-}
-
-__device__ __forceinline__ void bitonic_sort_packed(uint64_t* keys, int P)
-{
-	const int tid = threadIdx.x;
-	const int wave = tid >> 6, lane = tid & 63;
-	const int E = P / (WF_T / 64);      // elements owned by one wave when a pass is wave-local
-	const bool canLocal = E >= 512;     // >= 64 groups of 8 per wave
-	bool prevLocal = false;
-	for (int k = 2; k <= P; k <<= 1) {
-		int lj = 31 - __clz(k >> 1); // log2 of the first (largest) stride of this merge step
-		while (lj >= 0) {
-			const int S = lj >= 2 ? 3 : lj + 1;      // strides 2^lj .. 2^(lj-S+1)
-			const int ljmin = lj - S + 1;
-			const int groups = P >> S;
-			const bool local = canLocal && (2 << lj) <= E; // 2*jmax <= E: the pass stays inside each wave's chunk
-			if (!(local && prevLocal))
-				__syncthreads();
-			else {
-				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-			}
-			if (local) {
-				const int gpw = E >> S; // groups per wave
-				for (int g = wave * gpw + lane; g < (wave + 1) * gpw; g += 64) {
-					if (S == 3)
-						bitonic_pass<3>(keys, g, ljmin, k);
-					else if (S == 2)
-						bitonic_pass<2>(keys, g, ljmin, k);
-					else
-						bitonic_pass<1>(keys, g, ljmin, k);
-				}
-			} else {
-				for (int g = tid; g < groups; g += WF_T) {
-					if (S == 3)
-						bitonic_pass<3>(keys, g, ljmin, k);
-					else if (S == 2)
-						bitonic_pass<2>(keys, g, ljmin, k);
-					else
-						bitonic_pass<1>(keys, g, ljmin, k);
-				}
-			}
-			prevLocal = local;
-			lj -= S;
-		}
-	}
-	__syncthreads();
 }
 
 // neighbour offsets in the reference's enumeration order (utils/grid.cpp:29-47)
@@ -610,7 +515,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 	__shared__ uint32_t s_wcnt[64];              // ordered compaction: counts per (chunk row u, wave)
 	__shared__ uint64_t s_wtot[WF_W];
 	__shared__ uint32_t s_wsum[WF_W];
-	__shared__ uint32_t s_min, s_minNext[2], s_packFail, s_cand;
+	__shared__ uint32_t s_minNext[2], s_packFail, s_cand;
 	__shared__ int s_goal;
 	uint32_t* const hcell = reinterpret_cast<uint32_t*>(skey);          // [WF_HCAP] padded cell index + 1, 0 = empty
 	uint32_t* const hkey = reinterpret_cast<uint32_t*>(skey) + WF_HCAP; // [WF_HCAP] min (i*8+j)
@@ -689,7 +594,6 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			start = goalCells[g];
 		}
 		if (tid == 0) {
-			s_min = 0u; // cost bits of the start cell
 			s_minNext[0] = 0xFFFFFFFFu;
 			s_minNext[1] = 0xFFFFFFFFu;
 			s_packFail = 0;
