@@ -483,6 +483,24 @@ void ppo_hybrid_result_expanded(void* hv, int* cells3)
 		cells3[3 * i + 2] = h->last.expanded[i].theta;
 	}
 }
+/// Design studies: records the open-list pushes / pops of the next searches on this thread.
+static std::vector<FrontierEvent> g_trace;
+void ppo_trace_begin()
+{
+	g_trace.clear();
+	FrontierTraceSink() = &g_trace;
+}
+int64_t ppo_trace_end(int* kinds, double* costs, uint64_t* seqs, int64_t cap)
+{
+	FrontierTraceSink() = nullptr;
+	const int64_t n = (int64_t)g_trace.size();
+	for (int64_t i = 0; i < n && i < cap; i++) {
+		kinds[i] = g_trace[i].kind;
+		costs[i] = g_trace[i].cost;
+		seqs[i] = g_trace[i].seq;
+	}
+	return n;
+}
 /// Every node of the search tree in creation order: parent index, pose (3), {pathCost, totalCost}, dead flag.
 void ppo_hybrid_nodes(void* hv, int* parents, double* poses, double* costs, int* dead)
 {

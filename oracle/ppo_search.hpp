@@ -60,6 +60,18 @@ struct SortedFrontier {
 /// Binary min-heap on (cost, -seq): pops the smallest cost, and among equal
 /// costs the most recently pushed entry -- exactly the pop order of the
 /// reference Frontier (Appendix A Q1).  Entries may be lazily invalidated.
+/// Optional trace of open-list traffic (design studies of the device open list): +1 = push, -1 = pop.
+struct FrontierEvent {
+	int kind;
+	double cost;
+	unsigned long long seq;
+};
+inline std::vector<FrontierEvent>*& FrontierTraceSink()
+{
+	static thread_local std::vector<FrontierEvent>* sink = nullptr;
+	return sink;
+}
+
 template <typename CostT>
 struct LifoHeap {
 	struct Entry {
@@ -79,6 +91,9 @@ struct LifoHeap {
 	void Push(CostT cost, uint32_t id)
 	{
 		Entry e { cost, nextSeq++, id };
+		if (sizeof(CostT) == sizeof(double)) // the graph search's open list (the obstacle wavefront uses float costs)
+			if (auto* t = FrontierTraceSink())
+				t->push_back({ 1, (double)cost, (unsigned long long)e.seq });
 		size_t i = h.size();
 		h.push_back(e);
 		while (i > 0) {
@@ -93,6 +108,9 @@ struct LifoHeap {
 	Entry Pop()
 	{
 		Entry top = h[0];
+		if (sizeof(CostT) == sizeof(double))
+			if (auto* t = FrontierTraceSink())
+				t->push_back({ -1, (double)top.cost, (unsigned long long)top.seq });
 		Entry last = h.back();
 		h.pop_back();
 		size_t n = h.size();
