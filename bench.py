@@ -92,12 +92,26 @@ def main():
     d_starts = torch.from_numpy(starts).to(dev)
     d_goals = torch.from_numpy(goals).to(dev)
     d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(dev)
+    step_records = []
+
     def finish(pl):
         res = pl.fetch_results()  # synchronises that planner's stream
         if world > 1:
-            # the only collective: gather of the fixed-size result records (RCCL all_gather)
-            sharding.gather_records(sharding.records_from_results(res, B), B * world, rank, world, device=dev)
+            step_records.append(sharding.records_from_results(res, B))
         return res
+
+    def gather_all():
+        # the only collective: ONE gather of the fixed-size result records of all the steps just run (RCCL all_gather).
+        # One launch per run rather than per step: a collective's kernel queues behind the persistent search grids like
+        # any other launch.
+        if world > 1 and step_records:
+            k = len(step_records)
+            rec = np.concatenate(step_records)  # [k * B, fields], step-major
+            rec = rec.reshape(k, B, -1).transpose(1, 0, 2).reshape(B, -1)  # one row per local query, k records wide
+            out = sharding.gather_records(rec, B * world, rank, world, device=dev)
+            step_records.clear()
+            return out
+        return None
 
     def run_steps(k):
         """k steps = k batches of B queries; up to n_streams of them in flight."""
@@ -113,6 +127,7 @@ def main():
         for done in pending:
             out = finish(done)
             timings.append(done.last_timings())
+        gather_all()
         return out, timings
 
     def sync_all():
