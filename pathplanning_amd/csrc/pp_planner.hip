@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase, HeapEntry* __restrict__ heapBase,
 	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, PathRec* __restrict__ pathBase,
 	DevResult* __restrict__ results, unsigned long long* __restrict__ prof, const SuspendRec* __restrict__ resume, const int* __restrict__ nResume,
-	const unsigned long long* __restrict__ mtBase)
+	const unsigned long long* __restrict__ mtBase, HeapEntry* __restrict__ bandBase, double bandInvW)
 {
 	// Two uses: (a) one block per query of the batch, buffers indexed by the query (resume == nullptr);
 	// (b) continuation of the queries the rows kernel suspended: one block per SuspendRec, buffers indexed by its slot.
@@ -197,12 +197,15 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	__shared__ int16_t c_action[kSlots];
 	__shared__ int s_rsChecks;
 	__shared__ HeapEntry s_spill[16]; // entries that left the front buffer during this expansion
+	__shared__ int s_bandCnt[kBands];       // f-bands of the open list (pp_search_device.hpp): entries per ring slot
+	__shared__ long long s_bandAbs[kBands]; //                                                  band served by the slot
 
 	const MapView& m = A.m;
 	const int P = A.prims.n;
 	const int maxNodes = A.maxNodes;
 	Node* nodes = nodesBase + slot * maxNodes;
 	HeapEntry* heap = heapBase + slot * maxNodes;
+	HeapEntry* bands = bandBase + slot * (size_t)(kBands * kBandCap);
 	uint32_t* keymap = keymapBase + slot * A.ks.size();
 	uint32_t* expanded = expandedBase + (size_t)q * maxNodes;
 	RsLogEntry* rsLog = rsLogBase + (size_t)q * kRsLogCap;
@@ -252,6 +255,13 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	heapTop.node = 0;
 	if (resume && heapSize > 0)
 		heapTop = heap[0]; // the whole open list was flushed into the heap when the query was suspended
+	for (int i = lane; i < kBands; i += 64) {
+		s_bandCnt[i] = 0;
+		s_bandAbs[i] = 0;
+	}
+	int nOutside = heapSize;              // open-list entries outside the front buffer (bands + heap + spill buffer)
+	unsigned long long lowK = heapTop.ckey; // lower bound of everything outside (exact after a refill)
+	unsigned int lowS = heapTop.nseq;
 	int nNodes = resume ? rec.nNodes : 1;
 	unsigned int seq = resume ? rec.seq : 1;
 	if (!resume) {
@@ -306,37 +316,35 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		if (nSpill == 0)
 			return;
 		__syncthreads();
-		bool needSift = false;
-		HeapEntry mine;
-		if (lane < nSpill) {
-			mine = s_spill[lane];
-			const int pos = heapSize + lane;
-			if (pos > 0) {
-				const int par = (pos - 1) >> 6;
-				// a parent slot that is itself being appended in this flush is compared by the fallback
-				if (par >= heapSize)
-					needSift = true;
-				else {
-					const HeapEntry pe = heap[par];
-					needSift = heap_before(mine, pe);
+		// every entry goes to the ring slot of its f-band when that slot is free or already serves the band and has
+		// room; else to the heap.  One lane routes them: band counters live in LDS, so nothing here waits for HBM
+		// except the occasional heap sift.
+		if (lane == 0) {
+			int hs = heapSize;
+			for (int i = 0; i < nSpill; i++) {
+				const HeapEntry e = s_spill[i];
+				const long long B = band_of_key(e.ckey, bandInvW);
+				const int sl = (int)(B & (kBands - 1));
+				const int cnt = s_bandCnt[sl];
+				if ((cnt == 0 || s_bandAbs[sl] == B) && cnt < kBandCap) {
+					bands[sl * kBandCap + cnt] = e;
+					s_bandCnt[sl] = cnt + 1;
+					s_bandAbs[sl] = B;
+					s_spill[i].node = 0xFFFFFFFFu; // marks "not in the heap" for the loop below
+				} else {
+					heap_push(heap, hs, e);
 				}
 			}
 		}
-		if (__ballot(needSift)) {
-			if (lane == 0) {
-				int hs = heapSize;
-				for (int i = 0; i < nSpill; i++)
-					heap_push(heap, hs, s_spill[i]);
-			}
-		} else if (lane < nSpill) {
-			heap[heapSize + lane] = mine;
-		}
+		__syncthreads();
 		for (int i = 0; i < nSpill; i++) {
 			const HeapEntry e = s_spill[i];
-			if (heapSize + i == 0 || heap_before(e, heapTop))
+			if (e.node == 0xFFFFFFFFu)
+				continue;
+			if (heapSize == 0 || heap_before(e, heapTop))
 				heapTop = e;
+			heapSize++;
 		}
-		heapSize += nSpill;
 		nSpill = 0;
 		__syncthreads();
 	};
@@ -344,22 +352,109 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		if (lane == 0)
 			s_spill[nSpill] = e;
 		nSpill++;
+		nOutside++;
+		if (key_before(e.ckey, e.nseq, lowK, lowS)) {
+			lowK = e.ckey;
+			lowS = e.nseq;
+		}
 		if (nSpill == 16)
 			flush_spills();
 	};
-
-	// ---- SearchPath main loop, a_star.h:337-345
-	while (frontCount > 0 || heapSize > 0 || nSpill > 0) {
-		flush_spills();
-		HeapEntry top;
-		const bool fromFront = frontCount > 0 && (heapSize == 0 || key_before(lane_read64(front.ckey, 0), lane_read(front.nseq, 0), heapTop.ckey, heapTop.nseq));
-		if (fromFront) {
-			top = front_pop(front, frontCount, lane);
+	// An entry joins the front buffer exactly when "front <= everything outside" demands or allows it: it beats the
+	// buffer's last entry (then it must; if the buffer is full that last entry leaves), or the buffer has room and the
+	// entry beats the lower bound of the outside part.  (Checked against oracle traces by a CPU model of this policy.)
+	auto push_open = [&](const HeapEntry& e) {
+		bool toFront = true;
+		if (frontCount < PP_FRONT_CAP)
+			toFront = nOutside == 0 || key_before(e.ckey, e.nseq, lowK, lowS) ||
+				(frontCount > 0 && key_before(e.ckey, e.nseq, lane_read64(front.ckey, frontCount - 1), lane_read(front.nseq, frontCount - 1)));
+		if (toFront) {
+			HeapEntry sp;
+			if (front_insert(front, frontCount, e, lane, sp))
+				spill(sp);
 		} else {
-			__syncthreads(); // earlier heap writes
-			top = heap_pop_wave(heap, heapSize, lane, heapTop);
+			spill(e);
+		}
+	};
+	// The front buffer ran empty: load the lowest band (all of it: one coalesced load), sort it in the wave, then pull in
+	// whatever the heap holds below the buffer's last entry.
+	auto refill = [&]() {
+		flush_spills();
+		long long bAbs = 0x7FFFFFFFFFFFFFFFll;
+		for (int i = lane; i < kBands; i += 64)
+			if (s_bandCnt[i] > 0 && s_bandAbs[i] < bAbs)
+				bAbs = s_bandAbs[i];
+		// lowest band over the slots
+		for (int off = 32; off > 0; off >>= 1) {
+			const long long o = __shfl_xor(bAbs, off, 64);
+			bAbs = o < bAbs ? o : bAbs;
+		}
+		bAbs = __shfl(bAbs, 0, 64);
+		if (bAbs != 0x7FFFFFFFFFFFFFFFll) {
+			const int sl = (int)(bAbs & (kBands - 1));
+			const int n = s_bandCnt[sl];
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+			__builtin_amdgcn_s_waitcnt(0); // lane 0's band stores
+			HeapEntry e;
+			e.ckey = ~0ull;
+			e.nseq = ~0u;
+			e.node = 0;
+			if (lane < n)
+				e = bands[sl * kBandCap + lane];
+			wave_sort_entries(e.ckey, e.nseq, e.node, lane);
+			front.ckey = e.ckey;
+			front.nseq = e.nseq;
+			front.node = e.node;
+			frontCount = n;
+			nOutside -= n;
+			__syncthreads();
+			if (lane == 0)
+				s_bandCnt[sl] = 0;
 			__syncthreads();
 		}
+		// heap entries that come before the buffer's last entry (or, with an empty buffer, the heap's best) move in
+		while (heapSize > 0 && (frontCount == 0 || key_before(heapTop.ckey, heapTop.nseq, lane_read64(front.ckey, frontCount - 1), lane_read(front.nseq, frontCount - 1)))) {
+			__syncthreads();
+			const HeapEntry he = heap_pop_wave(heap, heapSize, lane, heapTop);
+			__syncthreads();
+			nOutside--;
+			HeapEntry sp;
+			if (front_insert(front, frontCount, he, lane, sp))
+				spill(sp);
+		}
+		// exact lower bound of what is outside now: the heap's best, the start of every non-empty band, the spill buffer
+		lowK = heapSize > 0 ? heapTop.ckey : ~0ull;
+		lowS = heapSize > 0 ? heapTop.nseq : ~0u;
+		{
+			long long bl = 0x7FFFFFFFFFFFFFFFll;
+			for (int i = lane; i < kBands; i += 64)
+				if (s_bandCnt[i] > 0 && s_bandAbs[i] < bl)
+					bl = s_bandAbs[i];
+			unsigned long long bk = bl == 0x7FFFFFFFFFFFFFFFll ? ~0ull : cost_key((double)bl / bandInvW);
+			for (int off = 32; off > 0; off >>= 1) {
+				const unsigned long long o = (unsigned long long)__shfl_xor((long long)bk, off, 64);
+				bk = o < bk ? o : bk;
+			}
+			bk = (unsigned long long)__shfl((long long)bk, 0, 64);
+			if (bk < lowK || (bk == lowK && 0u < lowS)) {
+				lowK = bk;
+				lowS = 0u; // below every entry of that band
+			}
+		}
+		for (int i = 0; i < nSpill; i++) {
+			const HeapEntry e = s_spill[i];
+			if (key_before(e.ckey, e.nseq, lowK, lowS)) {
+				lowK = e.ckey;
+				lowS = e.nseq;
+			}
+		}
+	};
+
+	// ---- SearchPath main loop, a_star.h:337-345
+	while (frontCount > 0 || nOutside > 0) {
+		if (frontCount == 0)
+			refill();
+		const HeapEntry top = front_pop(front, frontCount, lane); // the front holds the global best entries
 		PP_STAMP(PH_POP);
 		const int ni = (int)top.node;
 		// ---- the popped node: from the staging of the previous expansion when it is one of its children
@@ -505,11 +600,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			}
 			if (base == 0) {
 				// probable next pop (head of the front buffer or of the heap) -> pfWord
-				int cand = -1;
-				if (frontCount > 0 && (heapSize == 0 || key_before(lane_read64(front.ckey, 0), lane_read(front.nseq, 0), heapTop.ckey, heapTop.nseq)))
-					cand = (int)lane_read(front.node, 0);
-				else if (heapSize > 0)
-					cand = (int)heapTop.node;
+				const int cand = frontCount > 0 ? (int)lane_read(front.node, 0) : -1; // the front holds the global best
 				pfNode = cand;
 				pfDead = false;
 				if (cand >= 0 && lane < 24)
@@ -541,9 +632,24 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			// ---- insertion in child order, wave-uniform (a_star.h:391-402 + hybrid_a_star.h:199-205);
 			// every per-child value is read from its lane's registers (v_readlane), not from memory
 			const unsigned long long totalBits = (unsigned long long)__double_as_longlong(total);
-			for (int c = 0; c < cnt; c++) {
-				if (!lane_read(ok ? 1u : 0u, c))
-					continue;
+			// Most children change nothing (their cell is explored, or holds an open-list node they do not beat): every
+			// lane settles that for its own child, and only the children that push, replace, share a cell with an
+			// earlier child of the batch or lack the prefetched record walk the serial path below, in child order.
+			bool need = false;
+			if (lane < cnt && ok) {
+				if (dup || st == 0u)
+					need = true;
+				else if (st != kExplored) {
+					if (fpFor == st) {
+						const Pose fpp = { fpx, fpy, fpt };
+						need = identical_poses(fpp, child) && fptot > total; // ProcessPossibleShortcut would replace it
+					} else {
+						need = true;
+					}
+				}
+			}
+			for (unsigned long long todo = __ballot(need); todo; todo &= todo - 1ull) {
+				const int c = __ffsll((long long)todo) - 1;
 				const uint32_t ckey = lane_read(key, c);
 				uint32_t cst = lane_read(st, c);
 				if (lane_read(dup ? 1u : 0u, c)) {
@@ -601,9 +707,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 					e.nseq = 0xFFFFFFFFu - seq;
 					seq++;
 					e.node = (uint32_t)idx;
-					HeapEntry sp;
-					if (front_insert(front, frontCount, e, lane, sp))
-						spill(sp);
+					push_open(e);
 				}
 			}
 			PP_STAMP(PH_INSERT);
@@ -799,9 +903,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 						e.nseq = 0xFFFFFFFFu - seq;
 						seq++;
 						e.node = (uint32_t)idx;
-						HeapEntry sp;
-						if (front_insert(front, frontCount, e, lane, sp))
-							spill(sp);
+						push_open(e);
 					}
 				}
 				wave_lds_sync();
@@ -874,6 +976,8 @@ struct pp_planner {
 	SuspendRec* suspended = nullptr;        // [2][extraSlots] queries set aside by the first / second pass of the rows kernel
 	int32_t* order = nullptr;               // [maxBatch] query indices, probable longest first (rows kernel)
 	float* orderKeys = nullptr;             // [maxBatch] field value at each query's start pose (the sort key)
+	HeapEntry* bands = nullptr;             // [slots][kBands * kBandCap] f-bands of the open list (one-query-per-wave kernel)
+	double bandInvW = 16.0;                 // bands are 1 / bandInvW wide in total cost
 	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
 	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
 	bool rowsKernel = false;                // four-queries-per-wave kernel (throughput) vs one query per wave (latency)
@@ -896,7 +1000,7 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
-	void* ptrs[] = { p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->bands, p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -1090,6 +1194,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->suspended, 2 * (size_t)(A.listCap > 0 ? A.listCap : 1) * sizeof(SuspendRec));
 	alloc((void**)&p->mtStates, (p->rowsKernel ? S : 1) * Mt64::N * sizeof(unsigned long long));
 	alloc((void**)&p->nodes, S * N * sizeof(Node));
+	alloc((void**)&p->bands, S * (size_t)(kBands * kBandCap) * sizeof(HeapEntry));
 	alloc((void**)&p->heaps, S * N * sizeof(HeapEntry));
 	alloc((void**)&p->keymaps, S * A.ks.size() * 4);
 	alloc((void**)&p->expanded, B * N * 4);
@@ -1219,13 +1324,13 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		if (secondPass || cap1 > 0) // whatever is still set aside: one wave per query (the block count is read on the device)
 			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.listCap), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
-				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates);
+				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates, planner->bands, planner->bandInvW);
 	} else if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr);
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW);
 	else
 		hipLaunchKernelGGL(k_hybrid_search<false>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr);
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW);
 	PP_HIP_TRY(hipGetLastError());
 	PP_HIP_TRY(hipEventRecord(planner->e2, s));
 	planner->lastBatch = n_queries;

@@ -554,9 +554,30 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			// ---- insertion in child order (a_star.h:391-402 + hybrid_a_star.h:199-205): the four rows walk their
 			// children c = 0, 1, ... together
 			const int cnt = min(kRowLanes, P - base);
-			for (int c = 0; c < cnt; c++) {
+			// Most children change nothing (their cell is explored, or holds an open-list node they do not beat): every
+			// lane settles that for its own child, and only the children that push, replace, share a cell with an
+			// earlier child of the batch or lack the prefetched record walk the serial path, in child order.
+			bool need = false;
+			if (rl < cnt && ok) {
+				if (dup || st == 0u)
+					need = true;
+				else if (st != kExplored) {
+					if (fpFor == st) {
+						const Pose fpp = { fpx, fpy, fpt };
+						need = identical_poses(fpp, child) && fptot > total; // ProcessPossibleShortcut would replace it
+					} else {
+						need = true;
+					}
+				}
+			}
+			const unsigned long long needAll = __ballot(need);
+			const uint32_t rowNeed = row_bits(needAll, lane);
+			uint32_t todo = (uint32_t)(needAll | (needAll >> 16) | (needAll >> 32) | (needAll >> 48)) & 0xFFFFu; // children some row must walk
+			todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);
+			for (; todo; todo &= todo - 1u) {
+				const int c = __ffs((int)todo) - 1;
 				const uint32_t flags = c_flags[sb + c];
-				if (!(flags & 1u) || capacity)
+				if (!((rowNeed >> c) & 1u) || !(flags & 1u) || capacity)
 					continue;
 				const uint32_t ckey = c_key[sb + c];
 				uint32_t cst = c_state[sb + c];
