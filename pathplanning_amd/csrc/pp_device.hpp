@@ -258,6 +258,53 @@ PPD_INLINE bool is_path_valid(const MapView& m, const PathT& path, const Pose& i
 	return true;
 }
 
+/// Same march when the validity / obstacle distance of the path's start pose is already known (firstDist < 0: the
+/// start pose is invalid): the first sample of every child arc is the parent's pose, which was checked when the parent
+/// node was created, so the march starts without waiting for a distance load.  Counts that sample like the reference.
+template <typename PathT>
+PPD_INLINE bool is_path_valid_from(const MapView& m, const PathT& path, const Pose& init, float firstDist, float& last, int& checks)
+{
+	const double pathLength = path.length;
+	if (pathLength == 0.0) {
+		last = 1.0f;
+		checks++;
+		return !(firstDist < 0.0f);
+	}
+	checks++;
+	if (firstDist < 0.0f) {
+		last = 0.0f; // (float)(0.0 / pathLength)
+		return false;
+	}
+	float distance = firstDist;
+	double lastValidLength = 0.0;
+	double length = 0.0;
+	{
+		const float distToMapBorder = fmin4(init.x - m.lbx, m.ubx - init.x, init.y - m.lby, m.uby - init.y);
+		float deltaLength = distance - m.minSafeRadius;
+		deltaLength = fminf(deltaLength, distToMapBorder);
+		length += (double)fmaxf(deltaLength, m.minInterp);
+	}
+	while (length < pathLength) {
+		if (checks > (1 << 22)) {
+			last = (float)(lastValidLength / pathLength);
+			return false;
+		}
+		Pose s = path.interpolate(length / pathLength);
+		checks++;
+		if (!is_state_valid(m, s.x, s.y, s.t, distance)) {
+			last = (float)(lastValidLength / pathLength);
+			return false;
+		}
+		lastValidLength = length;
+		float distToMapBorder = fmin4(s.x - m.lbx, m.ubx - s.x, s.y - m.lby, m.uby - s.y);
+		float deltaLength = distance - m.minSafeRadius;
+		deltaLength = fminf(deltaLength, distToMapBorder);
+		length += (double)fmaxf(deltaLength, m.minInterp);
+	}
+	last = 1.0f;
+	return true;
+}
+
 /// HybridAStar::StatePropagator::GetVoronoiCost, algo/hybrid_a_star.cpp:93-109.
 /// The reference overwrites (`=`, not `+=`) the cost at every sample, so only the LAST
 /// sample survives (Appendix A Q8); it is then multiplied by the diagonal resolution (float).

@@ -36,7 +36,10 @@ struct Node { // 96 bytes
 	uint32_t key;      // packed discrete pose
 	int16_t action;    // -1 root, 0..P-1 constant-steer primitive, 1000 + word for Reeds-Shepp
 	uint8_t dead;      // removed from the open list by ProcessPossibleShortcut
-	uint8_t pad[13];
+	uint8_t pad0;
+	float dist0;       // obstacle distance at this pose, < 0 when the pose is not a valid state: the first sample of every
+	                   // child arc's validity march (IsPathValid samples the start pose first) without a dependent load
+	uint8_t pad[8];
 };
 static_assert(sizeof(Node) == 96, "Node layout");
 
@@ -193,6 +196,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	// child popped right away is read back from LDS instead of HBM
 	__shared__ double c_x[kSlots], c_y[kSlots], c_t[kSlots], c_cost[kSlots], c_total[kSlots], c_len[kSlots], c_h[kSlots], c_sin[kSlots], c_cos[kSlots];
 	__shared__ uint32_t c_key[kSlots], c_state[kSlots];
+	__shared__ float c_d0[kSlots];
 	__shared__ uint8_t c_valid[kSlots];
 	__shared__ int16_t c_action[kSlots];
 	__shared__ int s_rsChecks;
@@ -286,6 +290,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			root.key = ok ? key : kNoKey;
 			root.action = -1;
 			root.dead = 0;
+			{
+				float d0;
+				root.dist0 = is_state_valid(m, start.x, start.y, start.t, d0) ? d0 : -1.0f;
+			}
 			nodes[0] = root;
 			if (ok)
 				keymap[key] = kExplored; // the root is inserted in the explored set at init (a_star.h:361)
@@ -460,6 +468,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		// ---- the popped node: from the staging of the previous expansion when it is one of its children
 		double px, py, pt, pPathCost, pH, pSin, pCos;
 		uint32_t pKey;
+		float pDist0;
 		bool pDead = false;
 		{
 			const unsigned long long hit = __ballot(myNode == ni);
@@ -473,6 +482,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				pSin = c_sin[slot];
 				pCos = c_cos[slot];
 				pKey = c_key[slot];
+				pDist0 = c_d0[slot];
 			} else if (ni == pfNode) {
 				auto dbl = [&](int wi) { return __hiloint2double((int)lane_read(pfWord, wi + 1), (int)lane_read(pfWord, wi)); };
 				px = dbl(0);
@@ -484,6 +494,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				pCos = dbl(16);
 				pKey = lane_read(pfWord, 19);
 				pDead = pfDead || ((lane_read(pfWord, 20) >> 16) & 0xFFu) != 0u;
+				pDist0 = __uint_as_float(lane_read(pfWord, 21));
 			} else {
 				const Node nd = nodes[ni];
 				px = nd.x;
@@ -495,6 +506,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				pCos = nd.cosT;
 				pKey = nd.key;
 				pDead = nd.dead != 0;
+				pDist0 = nd.dist0;
 			}
 		}
 		wave_lds_sync(); // staging is about to be overwritten
@@ -531,6 +543,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			Pose child = ppose;
 			double cs = pSin, cc = pCos;
 			double gcost = 0.0, total = 0.0, len = 0.0, hh = 0.0;
+			float d0 = -1.0f;
 			if (p < P) {
 				ArcSC a;
 				a.init = ppose;
@@ -555,7 +568,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				int checks = 0;
 				ok = true;
 				lanePathChecks++;
-				const bool pathValid = is_path_valid(m, a, a.init, lastValidRatio, checks);
+				// validity / distance of the child's own pose: the first march sample of ITS children (not a counted check)
+				float cd0;
+				d0 = is_state_valid(m, child.x, child.y, child.t, cd0) ? cd0 : -1.0f;
+				const bool pathValid = is_path_valid_from(m, a, a.init, pDist0, lastValidRatio, checks);
 				PP_STAMP(PH_DUP); // [diagnostic: look-up issue + validity march]
 				if (!pathValid) {
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
@@ -569,6 +585,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 						if (packed)
 							st = keymap[key];
 						hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
+						d0 = is_state_valid(m, child.x, child.y, child.t, cd0) ? cd0 : -1.0f;
 					}
 				}
 				laneStateChecks += checks;
@@ -626,6 +643,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			c_h[lane] = hh;
 			c_sin[lane] = cs;
 			c_cos[lane] = cc;
+			c_d0[lane] = d0;
 			myNode = -1;
 			wave_lds_sync();
 			PP_STAMP(PH_CHILD);
@@ -727,6 +745,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				nd.key = key;
 				nd.action = (int16_t)p;
 				nd.dead = 0;
+				nd.dist0 = d0;
 				nodes[myNode] = nd;
 			}
 			PP_STAMP(PH_WRITE);
@@ -823,6 +842,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 							c_h[kRsSlot] = hh;
 							c_sin[kRsSlot] = s_;
 							c_cos[kRsSlot] = c_;
+							{
+								float rd0;
+								c_d0[kRsSlot] = is_state_valid(m, child.x, child.y, child.t, rd0) ? rd0 : -1.0f;
+							}
 							c_state[kRsSlot] = keymap[key];
 							c_action[kRsSlot] = (int16_t)(1000 + word);
 						}
@@ -884,6 +907,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 							nd.key = ckey;
 							nd.action = c_action[kRsSlot];
 							nd.dead = 0;
+							nd.dist0 = c_d0[kRsSlot];
 							nodes[idx] = nd;
 							keymap[ckey] = (uint32_t)idx + 1u;
 							if (nRsLog < kRsLogCap) {

@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	__shared__ double c_x[kS], c_y[kS], c_t[kS], c_cost[kS], c_total[kS], c_len[kS], c_h[kS], c_sin[kS], c_cos[kS];
 	__shared__ double f_x[kS], f_y[kS], f_t[kS], f_tot[kS]; // open-list node already in the child's cell (shortcut test)
 	__shared__ uint32_t c_key[kS], c_state[kS], f_for[kS];
+	__shared__ float c_d0[kS]; // obstacle distance at the child's pose (< 0: invalid state), see Node::dist0
 	__shared__ uint8_t c_flags[kS], c_valid[kS]; // flags: 1 = valid child, 2 = an earlier child of the batch shares its cell
 	__shared__ int16_t c_action[kS];
 	__shared__ int s_rsChecks[kRowsPerWave];
@@ -269,6 +270,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 					root.key = ok ? key : kNoKey;
 					root.action = -1;
 					root.dead = 0;
+					{
+						float d0;
+						root.dist0 = is_state_valid(m, start.x, start.y, start.t, d0) ? d0 : -1.0f;
+					}
 					nodes[0] = root;
 					if (ok)
 						keymap[key] = kExplored; // the root is inserted in the explored set at init (a_star.h:361)
@@ -377,6 +382,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 		// prefetch of the probable next pop, else from HBM
 		double px, py, pt, pPathCost, pH, pSin, pCos;
 		uint32_t pKey;
+		float pDist0;
 		bool pDead = false;
 		{
 			const uint32_t hit = row_bits(__ballot(myNode == ni), lane);
@@ -390,6 +396,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				pSin = c_sin[sb + slot];
 				pCos = c_cos[sb + slot];
 				pKey = c_key[sb + slot];
+				pDist0 = c_d0[sb + slot];
 			} else if (ni == pfNode) {
 				// lane k of the row holds the k-th 8-byte word of the record (see the prefetch below)
 				auto d64 = [&](int k) { return __longlong_as_double((long long)row_read64(pf64, lane, k)); };
@@ -401,7 +408,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				pSin = d64(7);
 				pCos = d64(8);
 				pKey = (uint32_t)(row_read64(pf64, lane, 9) >> 32);                     // { parent, key }
-				pDead = pfDead || ((row_read64(pf64, lane, 10) >> 16) & 0xFFull) != 0ull; // { action, dead, pad }
+				pDead = pfDead || ((row_read64(pf64, lane, 10) >> 16) & 0xFFull) != 0ull; // { action, dead, pad, dist0 }
+				pDist0 = __uint_as_float((uint32_t)(row_read64(pf64, lane, 10) >> 32));
 			} else {
 				const Node nd = nodes[ni];
 				px = nd.x;
@@ -413,6 +421,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				pCos = nd.cosT;
 				pKey = nd.key;
 				pDead = nd.dead != 0;
+				pDist0 = nd.dist0;
 			}
 		}
 		wave_lds_sync(); // staging is about to be overwritten
@@ -452,6 +461,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			Pose child = ppose;
 			double cs = pSin, cc = pCos;
 			double gcost = 0.0, total = 0.0, len = 0.0, hh = 0.0;
+			float d0 = -1.0f;
 			if (p < P) {
 				ArcSC a;
 				a.init = ppose;
@@ -475,7 +485,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				int checks = 0;
 				ok = true;
 				lanePathChecks++;
-				const bool pathValid = is_path_valid(m, a, a.init, lastValidRatio, checks);
+				// validity / distance of the child's own pose: the first march sample of ITS children (not a counted check)
+				float cd0;
+				d0 = is_state_valid(m, child.x, child.y, child.t, cd0) ? cd0 : -1.0f;
+				const bool pathValid = is_path_valid_from(m, a, a.init, pDist0, lastValidRatio, checks);
 				if (!pathValid) {
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
@@ -488,6 +501,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 						if (packed)
 							st = keymap[key];
 						hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
+						d0 = is_state_valid(m, child.x, child.y, child.t, cd0) ? cd0 : -1.0f;
 					}
 				}
 				laneStateChecks += checks;
@@ -544,6 +558,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			c_h[sb + rl] = hh;
 			c_sin[sb + rl] = cs;
 			c_cos[sb + rl] = cc;
+			c_d0[sb + rl] = d0;
 			f_x[sb + rl] = fpx;
 			f_y[sb + rl] = fpy;
 			f_t[sb + rl] = fpt;
@@ -655,6 +670,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				nd.key = key;
 				nd.action = (int16_t)p;
 				nd.dead = 0;
+				nd.dist0 = d0;
 				nodes[myNode] = nd;
 			}
 		}
@@ -758,6 +774,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 							c_h[sb + kRowRs] = hh;
 							c_sin[sb + kRowRs] = s_;
 							c_cos[sb + kRowRs] = c_;
+							{
+								float rd0;
+								c_d0[sb + kRowRs] = is_state_valid(m, child.x, child.y, child.t, rd0) ? rd0 : -1.0f;
+							}
 							c_state[sb + kRowRs] = keymap[key];
 							c_action[sb + kRowRs] = (int16_t)(1000 + word);
 						}
@@ -820,6 +840,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 							nd.key = ckey;
 							nd.action = c_action[sb + kRowRs];
 							nd.dead = 0;
+							nd.dist0 = c_d0[sb + kRowRs];
 							nodes[idx] = nd;
 							keymap[ckey] = (uint32_t)idx + 1u;
 							if (nRsLog < kRsLogCap) {
