@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=192, help="queries timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--search-rows", type=int, default=8192, help="search rows shared by the batches in flight (8192 = every resident wave slot)")
+    ap.add_argument("--debug-skip", type=int, default=0, choices=(0, 1, 2),
+                    help="timing experiments only (the line is then marked invalid): after the warm-up drop the wavefront (1) or the search (2) from every step; "
+                         "with 1 the searches reuse the cost fields the warm-up left in each lane (same goals every step)")
     ap.add_argument("--streams", type=int, default=8, help="independent batches kept in flight (one planner + HIP stream each)")
     args = ap.parse_args()
 
@@ -138,6 +141,8 @@ def main():
     if args.warmup:
         run_steps(args.warmup)
     sync_all()
+    if args.debug_skip:
+        os.environ["PP_DEBUG_SKIP"] = str(args.debug_skip)
     t0 = time.perf_counter()
     res, timings = run_steps(args.steps)
     sync_all()
@@ -235,6 +240,7 @@ def main():
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
+            **({"INVALID_debug_skip": args.debug_skip} if args.debug_skip else {}),
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",

@@ -59,6 +59,8 @@ struct SuspendRec {
 	int32_t heapSize, nNodes, nExpanded, nRngDraws, nRsAttempts, nRsLog, mtIdx;
 	uint32_t seq;
 	long long stateChecks, pathChecks; // totals so far (arcs + Reeds-Shepp)
+	long long bandLo;                  // bottom of the f-band window (slot counts are saved next to the bands)
+	int32_t nOutside, pad;             // open-list entries in bands + heap
 };
 
 struct RsLogEntry {
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase, HeapEntry* __restrict__ heapBase,
 	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, PathRec* __restrict__ pathBase,
 	DevResult* __restrict__ results, unsigned long long* __restrict__ prof, const SuspendRec* __restrict__ resume, const int* __restrict__ nResume,
-	const unsigned long long* __restrict__ mtBase, HeapEntry* __restrict__ bandBase, double bandInvW)
+	const unsigned long long* __restrict__ mtBase, HeapEntry* __restrict__ bandBase, double bandInvW, uint8_t* __restrict__ bandMetaBase)
 {
 	// Two uses: (a) one block per query of the batch, buffers indexed by the query (resume == nullptr);
 	// (b) continuation of the queries the rows kernel suspended: one block per SuspendRec, buffers indexed by its slot.
@@ -201,8 +203,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	__shared__ int16_t c_action[kSlots];
 	__shared__ int s_rsChecks;
 	__shared__ HeapEntry s_spill[16]; // entries that left the front buffer during this expansion
-	__shared__ int s_bandCnt[kBands];       // f-bands of the open list (pp_search_device.hpp): entries per ring slot
-	__shared__ long long s_bandAbs[kBands]; //                                                  band served by the slot
+	__shared__ uint8_t s_bandCnt[kBands]; // f-bands of the open list (pp_search_device.hpp): entries per ring slot
 
 	const MapView& m = A.m;
 	const int P = A.prims.n;
@@ -259,13 +260,18 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	heapTop.node = 0;
 	if (resume && heapSize > 0)
 		heapTop = heap[0]; // the whole open list was flushed into the heap when the query was suspended
-	for (int i = lane; i < kBands; i += 64) {
-		s_bandCnt[i] = 0;
-		s_bandAbs[i] = 0;
-	}
-	int nOutside = heapSize;              // open-list entries outside the front buffer (bands + heap + spill buffer)
-	unsigned long long lowK = heapTop.ckey; // lower bound of everything outside (exact after a refill)
-	unsigned int lowS = heapTop.nseq;
+	// band window: fresh queries start it a little below the root's band; a resumed query brings its window and the
+	// slot counts (saved next to the bands when it was set aside)
+	uint8_t* const bandMeta = reinterpret_cast<uint8_t*>(bandMetaBase) + slot * (size_t)kBands;
+	for (int i = lane; i < kBands; i += 64)
+		s_bandCnt[i] = resume ? bandMeta[i] : (uint8_t)0;
+	long long bandLo = resume ? rec.bandLo : 0;
+	bool bandLoSet = resume != nullptr;
+	int nOutside = resume ? rec.nOutside : 0; // open-list entries outside the front buffer (bands + heap + spill buffer)
+	// lower bound of everything outside (a resumed query starts with the lowest possible bound: nothing enters the empty
+	// front buffer before the first refill)
+	unsigned long long lowK = resume ? 0ull : ~0ull;
+	unsigned int lowS = resume ? 0u : ~0u;
 	int nNodes = resume ? rec.nNodes : 1;
 	unsigned int seq = resume ? rec.seq : 1;
 	if (!resume) {
@@ -334,10 +340,9 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				const long long B = band_of_key(e.ckey, bandInvW);
 				const int sl = (int)(B & (kBands - 1));
 				const int cnt = s_bandCnt[sl];
-				if ((cnt == 0 || s_bandAbs[sl] == B) && cnt < kBandCap) {
+				if (B >= bandLo && B < bandLo + kBands && cnt < kBandCap) {
 					bands[sl * kBandCap + cnt] = e;
-					s_bandCnt[sl] = cnt + 1;
-					s_bandAbs[sl] = B;
+					s_bandCnt[sl] = (uint8_t)(cnt + 1);
 					s_spill[i].node = 0xFFFFFFFFu; // marks "not in the heap" for the loop below
 				} else {
 					heap_push(heap, hs, e);
@@ -357,6 +362,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		__syncthreads();
 	};
 	auto spill = [&](const HeapEntry& e) {
+		if (!bandLoSet) { // the window starts one cost unit below the first entry that leaves the front buffer
+			bandLo = (band_of_key(e.ckey, bandInvW) - 64) & ~3ll;
+			bandLoSet = true;
+		}
 		if (lane == 0)
 			s_spill[nSpill] = e;
 		nSpill++;
@@ -388,27 +397,35 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	// whatever the heap holds below the buffer's last entry.
 	auto refill = [&]() {
 		flush_spills();
+		// lowest non-empty band: the slots are scanned in ring order from the window's bottom, 64 per step (entries
+		// cluster right above the current cost, so the first step nearly always hits)
 		long long bAbs = 0x7FFFFFFFFFFFFFFFll;
-		for (int i = lane; i < kBands; i += 64)
-			if (s_bandCnt[i] > 0 && s_bandAbs[i] < bAbs)
-				bAbs = s_bandAbs[i];
-		// lowest band over the slots
-		for (int off = 32; off > 0; off >>= 1) {
-			const long long o = __shfl_xor(bAbs, off, 64);
-			bAbs = o < bAbs ? o : bAbs;
+		for (int step = 0; step < kBands / 64; step++) {
+			const long long b = bandLo + step * 64 + lane;
+			const unsigned long long hitm = __ballot(s_bandCnt[(int)(b & (kBands - 1))] > 0);
+			if (hitm) {
+				bAbs = bandLo + step * 64 + (__ffsll((long long)hitm) - 1);
+				break;
+			}
 		}
-		bAbs = __shfl(bAbs, 0, 64);
+		long long loadedTop = bandLo - 1; // highest band that has certainly been emptied
 		if (bAbs != 0x7FFFFFFFFFFFFFFFll) {
-			const int sl = (int)(bAbs & (kBands - 1));
-			const int n = s_bandCnt[sl];
+			// the 64 lanes take the aligned group of four consecutive bands that contains the lowest one (4 x 16 entries,
+			// contiguous in memory): lane l -> band (group << 2 | l >> 4), entry l & 15
+			const long long bn = ((bAbs >> 2) << 2) | (long long)(lane >> 4);
+			const int sl = (int)(bn & (kBands - 1));
+			const int cntSl = s_bandCnt[sl];
+			const bool mineBand = cntSl > 0 && bn >= bandLo && bn < bandLo + kBands;
+			const bool have = mineBand && (lane & 15) < cntSl;
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 			__builtin_amdgcn_s_waitcnt(0); // lane 0's band stores
 			HeapEntry e;
 			e.ckey = ~0ull;
 			e.nseq = ~0u;
 			e.node = 0;
-			if (lane < n)
-				e = bands[sl * kBandCap + lane];
+			if (have)
+				e = bands[sl * kBandCap + (lane & 15)];
+			const int n = __popcll(__ballot(have));
 			wave_sort_entries(e.ckey, e.nseq, e.node, lane);
 			front.ckey = e.ckey;
 			front.nseq = e.nseq;
@@ -416,9 +433,11 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			frontCount = n;
 			nOutside -= n;
 			__syncthreads();
-			if (lane == 0)
+			if (mineBand && (lane & 15) == 0)
 				s_bandCnt[sl] = 0;
 			__syncthreads();
+			bandLo = bAbs & ~3ll;           // every band below the lowest one was empty: the window moves up (multiple of 4)
+			loadedTop = ((bAbs >> 2) << 2) | 3; // the group's bands inside the window are empty now
 		}
 		// heap entries that come before the buffer's last entry (or, with an empty buffer, the heap's best) move in
 		while (heapSize > 0 && (frontCount == 0 || key_before(heapTop.ckey, heapTop.nseq, lane_read64(front.ckey, frontCount - 1), lane_read(front.nseq, frontCount - 1)))) {
@@ -430,20 +449,12 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			if (front_insert(front, frontCount, he, lane, sp))
 				spill(sp);
 		}
-		// exact lower bound of what is outside now: the heap's best, the start of every non-empty band, the spill buffer
+		// lower bound of what is outside now: the heap's best, the start of the first band that was not loaded, the spill
+		// buffer
 		lowK = heapSize > 0 ? heapTop.ckey : ~0ull;
 		lowS = heapSize > 0 ? heapTop.nseq : ~0u;
 		{
-			long long bl = 0x7FFFFFFFFFFFFFFFll;
-			for (int i = lane; i < kBands; i += 64)
-				if (s_bandCnt[i] > 0 && s_bandAbs[i] < bl)
-					bl = s_bandAbs[i];
-			unsigned long long bk = bl == 0x7FFFFFFFFFFFFFFFll ? ~0ull : cost_key((double)bl / bandInvW);
-			for (int off = 32; off > 0; off >>= 1) {
-				const unsigned long long o = (unsigned long long)__shfl_xor((long long)bk, off, 64);
-				bk = o < bk ? o : bk;
-			}
-			bk = (unsigned long long)__shfl((long long)bk, 0, 64);
+			const unsigned long long bk = cost_key((double)(loadedTop + 1) / bandInvW);
 			if (bk < lowK || (bk == lowK && 0u < lowS)) {
 				lowK = bk;
 				lowS = 0u; // below every entry of that band
@@ -1000,8 +1011,9 @@ struct pp_planner {
 	SuspendRec* suspended = nullptr;        // [2][extraSlots] queries set aside by the first / second pass of the rows kernel
 	int32_t* order = nullptr;               // [maxBatch] query indices, probable longest first (rows kernel)
 	float* orderKeys = nullptr;             // [maxBatch] field value at each query's start pose (the sort key)
-	HeapEntry* bands = nullptr;             // [slots][kBands * kBandCap] f-bands of the open list (one-query-per-wave kernel)
-	double bandInvW = 16.0;                 // bands are 1 / bandInvW wide in total cost
+	HeapEntry* bands = nullptr;             // [slots][kBands * kBandCap] f-bands of the open list
+	uint8_t* bandMeta = nullptr;            // [slots][kBands] slot fill counts of set-aside queries
+	double bandInvW = 64.0;                 // bands are 1 / bandInvW wide in total cost
 	int searchWaves = 0;                    // resident waves of k_hybrid_search_rows on this device
 	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
 	bool rowsKernel = false;                // four-queries-per-wave kernel (throughput) vs one query per wave (latency)
@@ -1024,7 +1036,7 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
-	void* ptrs[] = { p->bands, p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->bandMeta, p->bands, p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -1219,6 +1231,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->mtStates, (p->rowsKernel ? S : 1) * Mt64::N * sizeof(unsigned long long));
 	alloc((void**)&p->nodes, S * N * sizeof(Node));
 	alloc((void**)&p->bands, S * (size_t)(kBands * kBandCap) * sizeof(HeapEntry));
+	alloc((void**)&p->bandMeta, S * (size_t)kBands);
 	alloc((void**)&p->heaps, S * N * sizeof(HeapEntry));
 	alloc((void**)&p->keymaps, S * A.ks.size() * 4);
 	alloc((void**)&p->expanded, B * N * 4);
@@ -1314,7 +1327,8 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	static const bool lpt = !(getenv("PP_SEARCH_ORDER") && getenv("PP_SEARCH_ORDER")[0] == '0');
 	const bool ordered = planner->rowsKernel && lpt && n_queries <= 4096 && n_queries > planner->searchRows;
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
-	static const int dbgSkip = getenv("PP_DEBUG_SKIP") ? atoi(getenv("PP_DEBUG_SKIP")) : 0; // timing experiments only: 1 = no wavefront, 2 = no search
+	const char* const dbgEnv = getenv("PP_DEBUG_SKIP"); // timing experiments only (bench.py --debug-skip): 1 = no wavefront, 2 = no search
+	const int dbgSkip = dbgEnv ? atoi(dbgEnv) : 0;
 	if (dbgSkip != 1)
 	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
 		planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true, ordered ? starts_dev : nullptr, ordered ? planner->order : nullptr,
@@ -1333,7 +1347,7 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		const int cap1 = planner->args.suspendAfter, cap2 = planner->args.suspendAfter2, cpt = planner->compactBelow;
 		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(grid), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
 			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, ctl, list1,
-			ordered ? planner->order : nullptr, cap1, nullptr, nullptr, ctl + 1, spare, cpt);
+			ordered ? planner->order : nullptr, cap1, nullptr, nullptr, ctl + 1, spare, cpt, planner->bands, planner->bandInvW, planner->bandMeta);
 		PP_HIP_TRY(hipGetLastError());
 		const bool secondPass = cpt > 0 || (cap1 > 0 && cap2 > cap1);
 		if (secondPass) {
@@ -1342,19 +1356,20 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 			const int waves2 = (planner->args.listCap + kRowsPerWave - 1) / kRowsPerWave;
 			hipLaunchKernelGGL(k_hybrid_search_rows, dim3(waves2 < wavesMax ? waves2 : wavesMax), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates,
-				planner->results, ctl + 2, list2, nullptr, cap2 > cap1 ? cap2 : 0, list1, ctl + 1, ctl + 3, spare, cpt > 0 ? 1 : 0);
+				planner->results, ctl + 2, list2, nullptr, cap2 > cap1 ? cap2 : 0, list1, ctl + 1, ctl + 3, spare, cpt > 0 ? 1 : 0, planner->bands, planner->bandInvW,
+				planner->bandMeta);
 			PP_HIP_TRY(hipGetLastError());
 		}
 		if (secondPass || cap1 > 0) // whatever is still set aside: one wave per query (the block count is read on the device)
 			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.listCap), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
-				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates, planner->bands, planner->bandInvW);
+				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates, planner->bands, planner->bandInvW, planner->bandMeta);
 	} else if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW);
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW, planner->bandMeta);
 	else
 		hipLaunchKernelGGL(k_hybrid_search<false>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW);
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW, planner->bandMeta);
 	PP_HIP_TRY(hipGetLastError());
 	PP_HIP_TRY(hipEventRecord(planner->e2, s));
 	planner->lastBatch = n_queries;

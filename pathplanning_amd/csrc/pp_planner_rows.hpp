@@ -19,13 +19,18 @@
 // oracle (tests/test_gpu_hybrid.py checks the expanded sequence).
 #pragma once
 
+#ifndef PP_ROWS_EAGER_REFILL
+#define PP_ROWS_EAGER_REFILL 1
+#endif
+
 // --------------------------------------------------------------------------------------------------- kernel --
 __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_rows(SearchArgs A, int nQueries, const double* __restrict__ starts,
 	const double* __restrict__ goals, const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase,
 	HeapEntry* __restrict__ heapBase, uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase,
 	PathRec* __restrict__ pathBase, unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery,
 	SuspendRec* __restrict__ suspended, const int32_t* __restrict__ order, int suspendAfter, const SuspendRec* __restrict__ resumeList,
-	const int* __restrict__ nResumeDev, int* __restrict__ suspendedCount, int* __restrict__ spareCount, int compactBelow)
+	const int* __restrict__ nResumeDev, int* __restrict__ suspendedCount, int* __restrict__ spareCount, int compactBelow, HeapEntry* __restrict__ bandBase, double bandInvW,
+	uint8_t* __restrict__ bandMetaBase)
 {
 	// Two uses.  (a) resumeList == nullptr: the rows take the batch's queries (nextQuery[0] counts them, order[] gives the
 	// hand-out order); a query that reaches `suspendAfter` expansions is written to suspended[] and its row continues in a
@@ -43,6 +48,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	HeapEntry* heap = heapBase + slot * A.maxNodes;
 	uint32_t* keymap = keymapBase + slot * A.ks.size();
 	unsigned long long* mt = mtBase + slot * Mt64::N;
+	HeapEntry* bands = bandBase + slot * (size_t)(kBands * kBandCap);
 	const int firstSpareSlot = A.searchRows; // spare slots follow the rows' own
 	bool noSuspend = false; // no spare slot was left for this query
 
@@ -58,6 +64,9 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	__shared__ int s_rsChecks[kRowsPerWave];
 	__shared__ HeapEntry s_spill[kRowsPerWave][kRowLanes];
 	HeapEntry* const spillBuf = s_spill[lane >> 4];
+	// f-bands of the open list (pp_search_device.hpp): entries per ring slot, four u8 counters per word
+	__shared__ __attribute__((aligned(16))) uint32_t s_bandCnt[kRowsPerWave][kBands / 4];
+	uint32_t* const bandCnt = s_bandCnt[lane >> 4];
 
 	const MapView& m = A.m;
 	const int P = A.prims.n;
@@ -75,6 +84,11 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	FrontLane front;
 	front_clear(front);
 	int frontCount = 0, heapSize = 0, nSpill = 0;
+	int nOutside = 0;              // open-list entries outside the front buffer (bands + heap + spill buffer)
+	long long bandLo = 0;          // bottom of the band window (multiple of 4), valid once bandLoSet
+	bool bandLoSet = false;
+	unsigned long long lowK = ~0ull; // lower bound of everything outside
+	uint32_t lowS = ~0u;
 	HeapEntry heapTop;
 	heapTop.ckey = ~0ull;
 	heapTop.nseq = ~0u;
@@ -87,50 +101,155 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	int status = -1, solutionNode = -1;
 	double solutionCost = __builtin_huge_val();
 
+	// Entries that leave the front buffer are staged in LDS (spillBuf) and flushed sixteen at a time: every lane routes
+	// one entry to the ring slot of its f-band (a slot's position comes from an LDS atomic on the packed counters), the
+	// rare ones outside the window or in a full slot go to the heap one by one.
 	auto flush_spills = [&]() { // row-uniform nSpill > 0
 		wave_lds_sync();
-		bool needSift = false;
-		HeapEntry mine;
-		mine.ckey = ~0ull;
-		mine.nseq = ~0u;
-		mine.node = 0;
+		bool toHeap = false;
 		if (rl < nSpill) {
-			mine = spillBuf[rl];
-			const int pos = heapSize + rl;
-			if (pos > 0) {
-				const int par = (pos - 1) >> 6;
-				if (par >= heapSize)
-					needSift = true; // a parent slot that is itself being appended in this flush
-				else {
-					const HeapEntry pe = heap[par];
-					needSift = heap_before(mine, pe);
+			const HeapEntry mine = spillBuf[rl];
+			const long long B = band_of_key(mine.ckey, bandInvW);
+			toHeap = true;
+			if (B >= bandLo && B < bandLo + kBands) {
+				const int sl = (int)(B & (kBands - 1)), sh = (sl & 3) * 8;
+				const uint32_t old = atomicAdd(&bandCnt[sl >> 2], 1u << sh);
+				const int pos = (int)((old >> sh) & 0xFFu);
+				if (pos < kBandCap) {
+					bands[sl * kBandCap + pos] = mine;
+					toHeap = false;
+				} else {
+					atomicSub(&bandCnt[sl >> 2], 1u << sh);
 				}
 			}
 		}
-		if (row_bits(__ballot(needSift), lane)) {
+		uint32_t hm = row_bits(__ballot(toHeap), lane);
+		if (hm) {
+			wave_vmem_sync(); // earlier heap writes
 			if (rl == 0) {
 				int hs = heapSize;
-				for (int i = 0; i < nSpill; i++)
-					heap_push(heap, hs, spillBuf[i]);
+				for (uint32_t mm = hm; mm; mm &= mm - 1)
+					heap_push(heap, hs, spillBuf[__ffs((int)mm) - 1]);
 			}
-		} else if (rl < nSpill) {
-			heap[heapSize + rl] = mine;
+			for (; hm; hm &= hm - 1) {
+				const HeapEntry e = spillBuf[__ffs((int)hm) - 1];
+				if (heapSize == 0 || heap_before(e, heapTop))
+					heapTop = e;
+				heapSize++;
+			}
 		}
-		for (int i = 0; i < nSpill; i++) {
-			const HeapEntry e = spillBuf[i];
-			if (heapSize + i == 0 || heap_before(e, heapTop))
-				heapTop = e;
-		}
-		heapSize += nSpill;
 		nSpill = 0;
+		wave_lds_sync();
 		wave_vmem_sync();
 	};
 	auto spill = [&](const HeapEntry& e) {
+		if (!bandLoSet) { // the window starts one cost unit below the first entry that leaves the front buffer
+			bandLo = (band_of_key(e.ckey, bandInvW) - 64) & ~3ll;
+			bandLoSet = true;
+		}
 		if (rl == 0)
 			spillBuf[nSpill] = e;
 		nSpill++;
+		nOutside++;
+		if (key_before(e.ckey, e.nseq, lowK, lowS)) {
+			lowK = e.ckey;
+			lowS = e.nseq;
+		}
 		if (nSpill == kRowLanes)
 			flush_spills();
+	};
+	// An entry joins the front buffer exactly when "front <= everything outside" demands or allows it (see the
+	// one-query-per-wave kernel's push_open)
+	auto push_open = [&](const HeapEntry& e) {
+		bool toFront = true;
+		if (frontCount < kRowLanes)
+			toFront = nOutside == 0 || key_before(e.ckey, e.nseq, lowK, lowS) ||
+				(frontCount > 0 && key_before(e.ckey, e.nseq, row_read64(front.ckey, lane, frontCount - 1), row_read(front.nseq, lane, frontCount - 1)));
+		if (toFront) {
+			HeapEntry sp;
+			if (front_insert_row(front, frontCount, e, rl, lane, sp))
+				spill(sp);
+		} else {
+			spill(e);
+		}
+	};
+	// The front buffer ran empty (row-uniform; nOutside > 0): load the lowest band -- one entry per lane --, sort it in the
+	// row, then pull in whatever the heap holds below the buffer's last entry.
+	auto refill = [&]() {
+		if (nSpill > 0)
+			flush_spills();
+		// lowest non-empty band: ring scan from the window's bottom, every lane looks at four slots (one word) per step
+		long long bAbs = 0x7FFFFFFFFFFFFFFFll;
+		const int w0 = (int)(bandLo >> 2);
+		for (int step = 0; step < kBands / 64; step++) {
+			const uint32_t w = bandCnt[(w0 + step * kRowLanes + rl) & (kBands / 4 - 1)];
+			const uint32_t hit = row_bits(__ballot(w != 0u), lane);
+			if (hit) {
+				const int fl = __ffs((int)hit) - 1;
+				const uint32_t wf = row_read(w, lane, fl);
+				bAbs = bandLo + 4ll * (step * kRowLanes + fl) + ((__ffs((int)wf) - 1) >> 3);
+				break;
+			}
+		}
+		long long loadedTop = bandLo - 1; // highest band that has certainly been emptied
+		if (bAbs != 0x7FFFFFFFFFFFFFFFll) {
+			const int sl = (int)(bAbs & (kBands - 1)), sh = (sl & 3) * 8;
+			const int n = (int)((bandCnt[sl >> 2] >> sh) & 0xFFu);
+			HeapEntry e;
+			e.ckey = ~0ull;
+			e.nseq = ~0u;
+			e.node = 0;
+			if (rl < n)
+				e = bands[sl * kBandCap + rl];
+			row_sort_entries(e.ckey, e.nseq, e.node, rl);
+			front.ckey = e.ckey;
+			front.nseq = e.nseq;
+			front.node = e.node;
+			frontCount = n;
+			nOutside -= n;
+			wave_lds_sync();
+			if (rl == 0)
+				bandCnt[sl >> 2] &= ~(0xFFu << sh);
+			wave_lds_sync();
+			bandLo = bAbs & ~3ll; // every band below the lowest one was empty: the window moves up
+			loadedTop = bAbs;
+		}
+		// heap entries that come before the buffer's last entry (or, with an empty buffer, the heap's best) move in
+		while (heapSize > 0 && (frontCount == 0 || key_before(heapTop.ckey, heapTop.nseq, row_read64(front.ckey, lane, frontCount - 1), row_read(front.nseq, lane, frontCount - 1)))) {
+			wave_vmem_sync();
+			const HeapEntry he = heap_pop_row(heap, heapSize, rl, lane, heapTop);
+			wave_vmem_sync();
+			nOutside--;
+			HeapEntry sp;
+			if (front_insert_row(front, frontCount, he, rl, lane, sp))
+				spill(sp);
+		}
+		// lower bound of what is outside now: the heap's best, the start of the first band that was not loaded, the spill buffer
+		lowK = heapSize > 0 ? heapTop.ckey : ~0ull;
+		lowS = heapSize > 0 ? heapTop.nseq : ~0u;
+		{
+			const unsigned long long bk = cost_key((double)(loadedTop + 1) / bandInvW);
+			if (bk < lowK || (bk == lowK && 0u < lowS)) {
+				lowK = bk;
+				lowS = 0u; // below every entry of that band
+			}
+		}
+		wave_lds_sync();
+		for (int i = 0; i < nSpill; i++) {
+			const HeapEntry e = spillBuf[i];
+			if (key_before(e.ckey, e.nseq, lowK, lowS)) {
+				lowK = e.ckey;
+				lowS = e.nseq;
+			}
+		}
+	};
+	auto set_slot = [&](size_t sl_) {
+		slot = sl_;
+		nodes = nodesBase + slot * A.maxNodes;
+		heap = heapBase + slot * A.maxNodes;
+		keymap = keymapBase + slot * A.ks.size();
+		mt = mtBase + slot * Mt64::N;
+		bands = bandBase + slot * (size_t)(kBands * kBandCap);
 	};
 	auto finish = [&]() { // writes the result record of the row's query and frees the row
 		const long long nStateChecks = row_sum_i64(laneStateChecks, lane) + rsStateChecks;
@@ -170,11 +289,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				// ---- continue a suspended query where it stopped, in the slot that holds its nodes / heap / key map / engine
 				const SuspendRec rec = resumeList[q];
 				q = rec.q;
-				slot = (size_t)rec.slot;
-				nodes = nodesBase + slot * A.maxNodes;
-				heap = heapBase + slot * A.maxNodes;
-				keymap = keymapBase + slot * A.ks.size();
-				mt = mtBase + slot * Mt64::N;
+				set_slot((size_t)rec.slot);
 				field = costFields + (size_t)q * A.fieldElems;
 				goal = { goals[3 * q], goals[3 * q + 1], wrap_theta(goals[3 * q + 2]) };
 				myNode = -1;
@@ -190,7 +305,21 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				heapTop.nseq = ~0u;
 				heapTop.node = 0;
 				if (heapSize > 0)
-					heapTop = heap[0]; // the whole open list was flushed into the heap at suspension
+					heapTop = heap[0];
+				// the open list was moved out of the front buffer at suspension: band window and slot counts come back, the
+				// lowest possible bound keeps everything out of the empty buffer until the first refill
+				{
+					const uint4* src = reinterpret_cast<const uint4*>(bandMetaBase + slot * (size_t)kBands);
+					wave_lds_sync();
+					for (int i = rl; i < kBands / 16; i += kRowLanes)
+						reinterpret_cast<uint4*>(bandCnt)[i] = src[i];
+					wave_lds_sync();
+				}
+				bandLo = rec.bandLo;
+				bandLoSet = true;
+				nOutside = rec.nOutside;
+				lowK = 0ull;
+				lowS = 0u;
 				nNodes = rec.nNodes;
 				seq = rec.seq;
 				nExpanded = rec.nExpanded;
@@ -236,6 +365,15 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				frontCount = 0;
 				heapSize = 0;
 				nSpill = 0;
+				nOutside = 0;
+				bandLo = 0;
+				bandLoSet = false;
+				lowK = ~0ull;
+				lowS = ~0u;
+				wave_lds_sync();
+				for (int i = rl; i < kBands / 4; i += kRowLanes)
+					bandCnt[i] = 0u;
+				wave_lds_sync();
 				heapTop.ckey = ~0ull;
 				heapTop.nseq = ~0u;
 				heapTop.node = 0;
@@ -297,12 +435,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			continue;
 
 		// ================= one step of SearchPath's main loop (a_star.h:337-345) for every active row =================
-		if (!(frontCount > 0 || heapSize > 0 || nSpill > 0)) {
+		if (!(frontCount > 0 || nOutside > 0)) {
 			finish(); // open list exhausted: status stays -1
 			continue;
 		}
-		if (nSpill > 0)
-			flush_spills();
 		// ---- setting a query aside: its open list goes entirely into the heap, the scalars into a SuspendRec of the next
 		// stage's list.  Two triggers: (a) the query reached `suspendAfter` expansions -- a row working on the batch then
 		// continues with the next query in a spare slot, a row working on a resume list takes the next record (and its
@@ -326,6 +462,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				if (rl == 0)
 					ns = atomicAdd(suspendedCount, 1);
 				ns = (int)row_read((uint32_t)ns, lane, 0); // < listCap: at most one record per row and spare slot
+				if (nSpill > 0)
+					flush_spills(); // the front's entries need the spill buffer
 				if (rl < frontCount) {
 					HeapEntry e;
 					e.ckey = front.ckey;
@@ -333,10 +471,21 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 					e.node = front.node;
 					spillBuf[rl] = e;
 				}
+				if (frontCount > 0 && !bandLoSet) {
+					bandLo = (band_of_key(row_read64(front.ckey, lane, 0), bandInvW) - 64) & ~3ll;
+					bandLoSet = true;
+				}
 				nSpill = frontCount;
+				nOutside += frontCount;
 				frontCount = 0;
+				wave_lds_sync();
 				if (nSpill > 0)
 					flush_spills();
+				{
+					uint4* dst = reinterpret_cast<uint4*>(bandMetaBase + slot * (size_t)kBands);
+					for (int i = rl; i < kBands / 16; i += kRowLanes)
+						dst[i] = reinterpret_cast<const uint4*>(bandCnt)[i];
+				}
 				const long long sc = row_sum_i64(laneStateChecks, lane) + rsStateChecks, pc = row_sum_i64(lanePathChecks, lane) + rsPathChecks;
 				if (rl == 0 && ns < A.listCap) {
 					SuspendRec r;
@@ -352,31 +501,28 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 					r.seq = seq;
 					r.stateChecks = sc;
 					r.pathChecks = pc;
+					r.bandLo = bandLo;
+					r.nOutside = nOutside;
+					r.pad = 0;
 					suspended[ns] = r;
 				}
 				if (compact) {
 					done = true; // nothing left to fetch: the wave ends once its rows have stored their records
 				} else if (!resumeList) {
-					slot = (size_t)firstSpareSlot + (size_t)sp;
-					nodes = nodesBase + slot * A.maxNodes;
-					heap = heapBase + slot * A.maxNodes;
-					keymap = keymapBase + slot * A.ks.size();
-					mt = mtBase + slot * Mt64::N;
+					set_slot((size_t)firstSpareSlot + (size_t)sp);
 				}
 				wave_vmem_sync();
 				act = false;
 				continue;
 			}
 		}
-		HeapEntry top;
-		const bool fromFront = frontCount > 0 && (heapSize == 0 || key_before(row_read64(front.ckey, lane, 0), row_read(front.nseq, lane, 0), heapTop.ckey, heapTop.nseq));
-		if (fromFront) {
-			top = front_pop_row(front, frontCount, lane);
-		} else {
-			wave_vmem_sync(); // earlier heap writes
-			top = heap_pop_row(heap, heapSize, rl, lane, heapTop);
-			wave_vmem_sync();
-		}
+		if (frontCount == 0)
+			refill();
+		const HeapEntry top = front_pop_row(front, frontCount, lane); // the front buffer holds the globally best entries
+#if PP_ROWS_EAGER_REFILL
+		if (frontCount == 0 && nOutside > 0)
+			refill(); // now rather than at the next pop: the prefetch below then knows the probable next node
+#endif
 		const int ni = (int)top.node;
 		// ---- the popped node: from the staging of the previous expansion when it is one of its children, else from the
 		// prefetch of the probable next pop, else from HBM
@@ -534,10 +680,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			if (base == 0) {
 				// probable next pop (head of the front buffer or of the heap): lane k < 11 fetches 8-byte word k of its record
 				int cand = -1;
-				if (frontCount > 0 && (heapSize == 0 || key_before(row_read64(front.ckey, lane, 0), row_read(front.nseq, lane, 0), heapTop.ckey, heapTop.nseq)))
+				if (frontCount > 0)
 					cand = (int)row_read(front.node, lane, 0);
-				else if (heapSize > 0)
-					cand = (int)heapTop.node;
 				pfNode = cand;
 				pfDead = false;
 				if (cand >= 0 && rl < 11)
@@ -649,9 +793,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 					e.nseq = 0xFFFFFFFFu - seq;
 					seq++;
 					e.node = (uint32_t)idx;
-					HeapEntry sp;
-					if (front_insert_row(front, frontCount, e, rl, lane, sp))
-						spill(sp);
+					push_open(e);
 				}
 			}
 			// ---- every lane writes the node record of its own child
@@ -860,9 +1002,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 						e.nseq = 0xFFFFFFFFu - seq;
 						seq++;
 						e.node = (uint32_t)idx;
-						HeapEntry sp;
-						if (front_insert_row(front, frontCount, e, rl, lane, sp))
-							spill(sp);
+						push_open(e);
 					}
 				}
 				wave_lds_sync();

@@ -133,6 +133,25 @@ PPD_INLINE HeapEntry front_pop_row(FrontLane& f, int& count, int lane)
 	count--;
 	return top;
 }
+/// sorts the 16 entries of a row ascending in (ckey, nseq): bitonic network, partners stay inside the row; keys are unique
+PPD_INLINE void row_sort_entries(unsigned long long& ckey, uint32_t& nseq, uint32_t& node, int rl)
+{
+#pragma unroll
+	for (int k = 2; k <= kRowLanes; k <<= 1) {
+#pragma unroll
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			const unsigned long long ok = ((unsigned long long)(uint32_t)__shfl_xor((int)(ckey >> 32), j, 64) << 32) | (uint32_t)__shfl_xor((int)ckey, j, 64);
+			const uint32_t os = (uint32_t)__shfl_xor((int)nseq, j, 64), on = (uint32_t)__shfl_xor((int)node, j, 64);
+			const bool up = (rl & k) == 0, lower = (rl & j) == 0;
+			const bool otherBefore = ok < ckey || (ok == ckey && os < nseq);
+			if ((lower == up) == otherBefore) {
+				ckey = ok;
+				nseq = os;
+				node = on;
+			}
+		}
+	}
+}
 /// 64-ary heap pop by the 16 lanes of a row (4 children per lane and level); see heap_pop_wave
 PPD_INLINE HeapEntry heap_pop_row(HeapEntry* heap, int& size, int rl, int lane, HeapEntry& cachedTop)
 {

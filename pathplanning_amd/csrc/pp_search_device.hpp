@@ -329,13 +329,17 @@ PPD_INLINE HeapEntry front_pop(FrontLane& f, int& count, int lane)
 // ------------------------------------------------------- open list: f-bands --
 // Outside the register front buffer the open list is kept in BANDS of the total cost f: band = floor(f / W).  A ring of
 // kBands slots x kBandCap entries per query in HBM holds the bands being filled (slot = band mod kBands, a slot serves
-// one band at a time, 256 KiB per query); what does not fit goes to the 64-ary heap.  The front buffer always holds the globally best
+// one band at a time); what does not fit goes to the 64-ary heap.  The front buffer always holds the globally best
 // entries (an entry enters a non-full front only if it beats a lower bound of everything outside), so a pop never needs
-// the heap, and an empty front is refilled with the whole lowest band: ONE coalesced 1 KiB load, sorted in the wave.
+// the heap, and an empty front is refilled with the whole lowest band: ONE coalesced load, sorted in the wave / row.
 // Measured motivation (tools/study_open_list.py): with the plain "most recent 64" buffer 70 % of the pops came from the
 // heap (two to three dependent HBM round trips each).
-constexpr int kBands = 256, kBandCap = 64; // with W = 1/16: a window of 16 cost units; the CPU model of this policy on
-                                            // oracle traces sends 0.15 % of the entries to the heap (32 bands of 1/4: 29 %)
+constexpr int kBandShift = 10, kBands = 1 << kBandShift, kBandCap = 16;
+// 1024 slots x 16 entries (256 KiB per query), W = 1/64: a window of 16 cost units that starts at `bandLo`, the lowest band
+// that may hold entries (slot = band & 1023 is unique inside the window; bands outside it go to the heap).  The CPU model of
+// the policy on oracle traces (tools/study_open_list.py) sends 0.65 % of the entries to the heap and refills a 16-entry
+// buffer once per ~6 pops.  A band is one entry per lane of a 16-lane row (k_hybrid_search_rows); the 64-lane kernel
+// loads the aligned group of four consecutive bands.  Slot fill counts (u8) live in LDS, 1 KiB per query.
 /// inverse of cost_key
 PPD_INLINE double key_cost(unsigned long long k)
 {
