@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libpphip.so")
+# PP_HIP_LIB: another build of the same library (tuning experiments: tools/build_variant.py)
+LIB_PATH = os.environ.get("PP_HIP_LIB") or os.path.join(HERE, "lib", "libpphip.so")
 
 c_dp = C.POINTER(C.c_double)
 c_fp = C.POINTER(C.c_float)

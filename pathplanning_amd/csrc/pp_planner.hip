@@ -105,6 +105,7 @@ struct SearchArgs {
 	int extraSlots;    // buffer slots beyond the rows' own, taken by rows whose query was set aside
 	int searchRows;    // rows the planner's buffers were sized for (spare slots start here)
 	int listCap;       // capacity of each SuspendRec list: one record per spare slot + one per row
+	int directCount;   // rows kernel: the first `directCount` queries of the hand-out order are not its own (they run one per wave)
 	size_t cells;
 	int64_t fieldElems; // floats per query in costFields (8 x 8-tiled obstacle-heuristic field)
 };
@@ -172,16 +173,22 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase, HeapEntry* __restrict__ heapBase,
 	uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase, PathRec* __restrict__ pathBase,
 	DevResult* __restrict__ results, unsigned long long* __restrict__ prof, const SuspendRec* __restrict__ resume, const int* __restrict__ nResume,
-	const unsigned long long* __restrict__ mtBase, HeapEntry* __restrict__ bandBase, double bandInvW, uint8_t* __restrict__ bandMetaBase)
+	const unsigned long long* __restrict__ mtBase, HeapEntry* __restrict__ bandBase, double bandInvW, uint8_t* __restrict__ bandMetaBase,
+	const int32_t* __restrict__ queryList, int slotBase)
 {
-	// Two uses: (a) one block per query of the batch, buffers indexed by the query (resume == nullptr);
-	// (b) continuation of the queries the rows kernel suspended: one block per SuspendRec, buffers indexed by its slot.
+	// Three uses: (a) one block per query of the batch, buffers indexed by the query (resume == nullptr, queryList == nullptr);
+	// (b) continuation of the queries the rows kernel suspended: one block per SuspendRec, buffers indexed by its slot;
+	// (c) the probable longest queries of a batch the rows kernel works on: block i takes query queryList[i] and buffer slot
+	// slotBase + i (nQueries = length of the list).
 	if (resume ? ((int)blockIdx.x >= *nResume || (int)blockIdx.x >= A.listCap) : (int)blockIdx.x >= nQueries)
 		return;
 	const SuspendRec rec = resume ? resume[blockIdx.x] : SuspendRec {};
-	const int q = resume ? rec.q : (int)blockIdx.x;
-	const size_t slot = resume ? (size_t)rec.slot : (size_t)q;
+	const int q = resume ? rec.q : (queryList ? queryList[blockIdx.x] : (int)blockIdx.x);
+	const size_t slot = resume ? (size_t)rec.slot : (queryList ? (size_t)slotBase + blockIdx.x : (size_t)q);
 	const int lane = threadIdx.x;
+#if PP_SEARCH_SETPRIO
+	__builtin_amdgcn_s_setprio(3); // see k_hybrid_search_rows
+#endif
 	unsigned long long phase[PH_COUNT] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 	unsigned long long tlast = 0;
 	if (kProfile)
@@ -1023,6 +1030,13 @@ struct pp_planner {
 	double *dStarts = nullptr, *dGoals = nullptr;
 	uint64_t* dSeeds = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+	// optional CU partition (PP_SEARCH_CUS / PP_WF_CUS): internal streams restricted to a subset of the compute units; the
+	// caller's stream waits for them, so the call keeps its stream-ordered meaning
+	hipStream_t searchStream = nullptr, wfStream = nullptr;
+	// the probable longest queries of a batch run one per wave next to the rows kernel (PP_SEARCH_DIRECT), on their own stream
+	hipStream_t directStream = nullptr;
+	hipEvent_t e3 = nullptr;
+	int directCount = 0;
 	float wavefrontMs = 0, searchMs = 0;
 	int lastBatch = 0;
 	std::vector<DevResult> hostResults;
@@ -1036,11 +1050,33 @@ void free_planner(pp_planner* p)
 {
 	if (!p)
 		return;
+#if PP_ROWS_STATS
+	{
+		unsigned long long h[24] = {};
+		if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rowsStats), sizeof h) == hipSuccess) {
+			fprintf(stderr, "[rows stats] wave iterations with 1/2/3/4 busy rows: %llu %llu %llu %llu\n", h[1], h[2], h[3], h[4]);
+			static const char* const names[14] = { "take", "set-aside", "pop+refill", "node", "child validity", "march", "truncate+cost", "cell-node+staging", "insert", "write", "rs", "endpoint", "keymap+heuristics", "voronoi" };
+			unsigned long long tot = 0, it = h[1] + h[2] + h[3] + h[4];
+			for (int i = 0; i < 14; i++)
+				tot += h[8 + i];
+			for (int i = 0; i < 14; i++)
+				fprintf(stderr, "[rows stats]   %-18s %5.1f %%  %8.0f clk / wave iteration\n", names[i], 100.0 * (double)h[8 + i] / (double)(tot ? tot : 1), (double)h[8 + i] / (double)(it ? it : 1));
+		}
+	}
+#endif
 	void* ptrs[] = { p->bandMeta, p->bands, p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
+	if (p->directStream)
+		(void)hipStreamDestroy(p->directStream);
+	if (p->e3)
+		(void)hipEventDestroy(p->e3);
+	if (p->searchStream)
+		(void)hipStreamDestroy(p->searchStream);
+	if (p->wfStream)
+		(void)hipStreamDestroy(p->wfStream);
 	if (p->e0)
 		(void)hipEventDestroy(p->e0);
 	if (p->e1)
@@ -1207,6 +1243,15 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		A.extraSlots = A.suspendAfter > 0 ? (ex ? atoi(ex) : (max_batch + 15) / 16) : 0; // queries that may be set aside (the rest stays)
 		A.searchRows = p->searchRows;
 		A.listCap = A.extraSlots + p->searchRows;
+		// A batch lasts as long as its longest query, and a query is a chain of dependent expansions: it runs faster alone in
+		// a wave (k_hybrid_search: ~11 us per expansion) than as one of four (rows kernel: 15-20 us).  The wavefront kernel
+		// already ranks the queries by probable length for the hand-out order; the first PP_SEARCH_DIRECT of that order get
+		// a wave of their own, in slots behind the spare ones.
+		const char* dc = getenv("PP_SEARCH_DIRECT");
+		p->directCount = p->rowsKernel ? (dc ? atoi(dc) : 0) : 0;
+		if (p->directCount < 0 || p->directCount > max_batch / 2)
+			p->directCount = 0;
+		A.directCount = 0; // set per call (only when the order is available)
 		// compaction (pp_planner_rows.hpp): waves whose queue is empty and that have at most this many busy rows re-queue
 		// their queries for a second pass that packs them four per wave.  Off by default: it issues fewer instructions
 		// (a wave costs the same with one busy row as with four) but the passes of one batch run one after the other, and
@@ -1226,7 +1271,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->wfError, 32); // control block: {wavefront error flag, wavefront goal counter, pass-1 query counter, pass-1 set-aside count,
 	                                // pass-2 record counter, pass-2 set-aside count}
 	// search buffers: one set per resident row (rows kernel) or per query (one-query-per-wave kernel)
-	const size_t S = p->rowsKernel ? (size_t)p->searchRows + (size_t)A.extraSlots : B;
+	const size_t S = p->rowsKernel ? (size_t)p->searchRows + (size_t)A.extraSlots + (size_t)p->directCount : B;
 	alloc((void**)&p->suspended, 2 * (size_t)(A.listCap > 0 ? A.listCap : 1) * sizeof(SuspendRec));
 	alloc((void**)&p->mtStates, (p->rowsKernel ? S : 1) * Mt64::N * sizeof(unsigned long long));
 	alloc((void**)&p->nodes, S * N * sizeof(Node));
@@ -1250,6 +1295,32 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		e = hipEventCreate(&p->e1);
 	if (e == hipSuccess)
 		e = hipEventCreate(&p->e2);
+	if (e == hipSuccess && p->directCount > 0)
+		e = hipEventCreateWithFlags(&p->e3, hipEventDisableTiming);
+	if (e == hipSuccess && p->directCount > 0)
+		e = hipStreamCreateWithFlags(&p->directStream, hipStreamNonBlocking);
+	{
+		// Compute-unit partition between the two kernels of a step.  Why: a wavefront workgroup needs 77 KB of LDS, two fit a CU
+		// -- unless a search wave (14 KB) is resident there, then only one does.  Search waves are few but spread over every
+		// CU, so they halve the wavefront kernels' residency wherever they land.  PP_SEARCH_CUS=n keeps the search on the first
+		// n CUs of the mask order (which interleaves XCDs and shader engines); PP_WF_CUS=k keeps the wavefront on the LAST k.
+		int dev = 0, nCu = 0;
+		(void)hipGetDevice(&dev);
+		(void)hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, dev);
+		auto masked = [&](int first, int count, hipStream_t* out) {
+			std::vector<uint32_t> mask((size_t)(nCu + 31) / 32, 0u);
+			for (int i = first; i < first + count && i < nCu; i++)
+				mask[(size_t)i / 32] |= 1u << (i % 32);
+			return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+		};
+		const char* sc = getenv("PP_SEARCH_CUS");
+		const char* wc = getenv("PP_WF_CUS");
+		const int nS = sc ? atoi(sc) : 0, nW = wc ? atoi(wc) : 0;
+		if (e == hipSuccess && nS > 0 && nS < nCu)
+			e = masked(0, nS, &p->searchStream);
+		if (e == hipSuccess && nW > 0 && nW < nCu)
+			e = masked(nCu - nW, nW, &p->wfStream);
+	}
 	if (e != hipSuccess) {
 		free_planner(p);
 		return pph::hip_fail(e, "planner allocation");
@@ -1329,11 +1400,30 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
 	const char* const dbgEnv = getenv("PP_DEBUG_SKIP"); // timing experiments only (bench.py --debug-skip): 1 = no wavefront, 2 = no search
 	const int dbgSkip = dbgEnv ? atoi(dbgEnv) : 0;
+	hipStream_t const ws = planner->wfStream ? planner->wfStream : s;
+	if (ws != s)
+		PP_HIP_TRY(hipStreamWaitEvent(ws, planner->e0, 0));
 	if (dbgSkip != 1)
-	PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
+	PP_HIP_TRY(pph::launch_wavefront(ws, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
 		planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true, ordered ? starts_dev : nullptr, ordered ? planner->order : nullptr,
 		planner->wfError + 6, planner->orderKeys));
-	PP_HIP_TRY(hipEventRecord(planner->e1, s));
+	PP_HIP_TRY(hipEventRecord(planner->e1, ws));
+	hipStream_t const callerStream = s;
+	if (planner->searchStream)
+		s = planner->searchStream; // the search kernels below go to the partition's stream
+	if (s != ws)
+		PP_HIP_TRY(hipStreamWaitEvent(s, planner->e1, 0));
+	const int nDirect = ordered && planner->directCount > 0 && dbgSkip != 2 ? (planner->directCount < n_queries / 2 ? planner->directCount : n_queries / 2) : 0;
+	planner->args.directCount = nDirect;
+	if (nDirect > 0) {
+		hipStream_t const ds = planner->directStream;
+		PP_HIP_TRY(hipStreamWaitEvent(ds, planner->e1, 0));
+		hipLaunchKernelGGL(k_hybrid_search<false>, dim3(nDirect), dim3(64), 0, ds, planner->args, nDirect, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
+			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands,
+			planner->bandInvW, planner->bandMeta, planner->order, planner->searchRows + planner->args.extraSlots);
+		PP_HIP_TRY(hipGetLastError());
+		PP_HIP_TRY(hipEventRecord(planner->e3, ds));
+	}
 	if (dbgSkip == 2) {
 	} else if (planner->rowsKernel) {
 		// four queries per wave, taken from a counter by a persistent grid (pp_planner_rows.hpp)
@@ -1363,15 +1453,19 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		if (secondPass || cap1 > 0) // whatever is still set aside: one wave per query (the block count is read on the device)
 			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.listCap), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
-				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates, planner->bands, planner->bandInvW, planner->bandMeta);
+				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates, planner->bands, planner->bandInvW, planner->bandMeta, nullptr, 0);
 	} else if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW, planner->bandMeta);
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW, planner->bandMeta, nullptr, 0);
 	else
 		hipLaunchKernelGGL(k_hybrid_search<false>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
-			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW, planner->bandMeta);
+			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW, planner->bandMeta, nullptr, 0);
 	PP_HIP_TRY(hipGetLastError());
+	if (nDirect > 0)
+		PP_HIP_TRY(hipStreamWaitEvent(s, planner->e3, 0)); // before e2: the search time covers both kernels
 	PP_HIP_TRY(hipEventRecord(planner->e2, s));
+	if (s != callerStream)
+		PP_HIP_TRY(hipStreamWaitEvent(callerStream, planner->e2, 0));
 	planner->lastBatch = n_queries;
 	return PP_OK;
 }

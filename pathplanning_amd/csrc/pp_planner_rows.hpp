@@ -19,6 +19,12 @@
 // oracle (tests/test_gpu_hybrid.py checks the expanded sequence).
 #pragma once
 
+#ifndef PP_ROWS_STATS
+#define PP_ROWS_STATS 0 // diagnostic build: histogram of busy rows per wave iteration, printed when a planner is destroyed
+#endif
+#if PP_ROWS_STATS
+__device__ unsigned long long g_rowsStats[24];
+#endif
 #ifndef PP_ROWS_EAGER_REFILL
 #define PP_ROWS_EAGER_REFILL 1
 #endif
@@ -37,6 +43,11 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	// spare slot (suspendedCount counts both).  (b) resumeList != nullptr: the rows take the records of that list
 	// (*nResumeDev of them) and continue those queries in the records' own slots; one that reaches `suspendAfter` is written
 	// to suspended[] again (for the one-query-per-wave kernel).
+#if PP_SEARCH_SETPRIO
+	// the searches are chains of dependent steps (a batch lasts as long as its longest query), the wavefront kernels they share
+	// the SIMDs with are throughput work: search waves issue first
+	__builtin_amdgcn_s_setprio(PP_ROWS_PRIO);
+#endif
 	const int lane = threadIdx.x;
 	const int rl = lane & (kRowLanes - 1);
 	const int sb = (lane >> 4) * kRowSlots; // first staging slot of this row
@@ -275,6 +286,27 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 		act = false;
 	};
 
+#if PP_ROWS_STATS
+	unsigned long long statIter[5] = { 0, 0, 0, 0, 0 }; // wave iterations by number of busy rows (diagnostic build)
+	// wave time by code region: the clock is read by the first active lane and booked to the region that just ended
+	// (rows diverge, so "last stamp" and the sums are wave-level values in LDS)
+	__shared__ unsigned long long s_phase[16], s_tlast;
+	if (lane < 16)
+		s_phase[lane] = 0ull;
+	if (lane == 0)
+		s_tlast = clock64();
+	wave_lds_sync();
+#define ROWS_STAMP(ph)                                                     \
+	{                                                                      \
+		const unsigned long long now_ = clock64();                        \
+		if (lane == __ffsll((long long)__ballot(true)) - 1) {             \
+			s_phase[ph] += now_ - s_tlast;                                \
+			s_tlast = now_;                                               \
+		}                                                                  \
+	}
+#else
+#define ROWS_STAMP(ph)
+#endif
 	for (;;) {
 		// ================= rows without a query take the next one =================
 		if (!act && !done) {
@@ -282,6 +314,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			if (rl == 0)
 				nq = atomicAdd(nextQuery, 1);
 			q = (int)row_read((uint32_t)nq, lane, 0);
+			if (!resumeList)
+				q += A.directCount; // the first entries of the hand-out order run one query per wave (k_hybrid_search)
 			const int nAvail = resumeList ? min(*nResumeDev, A.listCap) : nQueries;
 			if (q >= nAvail) {
 				done = true;
@@ -427,6 +461,11 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			}
 		}
 		const unsigned long long actMask = __ballot(act);
+#if PP_ROWS_STATS
+		if (lane == 0 && actMask)
+			statIter[__popcll(actMask) / kRowLanes]++;
+#endif
+		ROWS_STAMP(0) // taking queries
 		if (!actMask)
 			break; // every row has run out of queries
 		// compaction trigger (all lanes vote): some row found the queue empty and few rows of the wave are still busy
@@ -516,6 +555,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				continue;
 			}
 		}
+		ROWS_STAMP(1) // set-aside logic
 		if (frontCount == 0)
 			refill();
 		const HeapEntry top = front_pop_row(front, frontCount, lane); // the front buffer holds the globally best entries
@@ -523,6 +563,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 		if (frontCount == 0 && nOutside > 0)
 			refill(); // now rather than at the next pop: the prefetch below then knows the probable next node
 #endif
+		ROWS_STAMP(2) // pop + refill
 		const int ni = (int)top.node;
 		// ---- the popped node: from the staging of the previous expansion when it is one of its children, else from the
 		// prefetch of the probable next pop, else from HBM
@@ -599,6 +640,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			mtRaw = mt[mtIdx];
 
 		bool capacity = false;
+		ROWS_STAMP(3) // node record, solution test, bookkeeping
 		// ---- constant-steer children, reference order p = 2*deltaIndex + direction (hybrid_a_star.cpp:65-77)
 		for (int base = 0; base < P && !capacity; base += kRowLanes) {
 			const int p = base + rl;
@@ -619,14 +661,17 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				child = a.interpolate_sc(1.0, cs, cc);
 				int ix, iy, it;
 				discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+				ROWS_STAMP(11) // endpoint
 				// look-ups of the full-length child are issued before the validity march so that their latency
 				// overlaps it (they are redone only when the arc gets truncated)
 				bool packed = A.ks.pack(ix, iy, it, key);
 				if (packed)
 					st = keymap[key];
 				hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
+				ROWS_STAMP(12) // key map + heuristics
 				// Voronoi term of the full-length arc: its only map read (the last sample, Q8) is issued with the look-ups
 				const double voroFull = voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
+				ROWS_STAMP(13) // Voronoi term
 				float lastValidRatio;
 				int checks = 0;
 				ok = true;
@@ -634,7 +679,9 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				// validity / distance of the child's own pose: the first march sample of ITS children (not a counted check)
 				float cd0;
 				d0 = is_state_valid(m, child.x, child.y, child.t, cd0) ? cd0 : -1.0f;
+				ROWS_STAMP(4) // child's own validity
 				const bool pathValid = is_path_valid_from(m, a, a.init, pDist0, lastValidRatio, checks);
+				ROWS_STAMP(5) // validity march
 				if (!pathValid) {
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
@@ -662,6 +709,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 						ok = false; // outside the key map (cannot happen for poses inside the bounds)
 				}
 			}
+			ROWS_STAMP(6) // truncation, costs
 			if (ok && key == pKey)
 				st = kExplored; // the parent's cell was marked explored just above (a_star.h:381)
 			// open-list node already in this child's cell: its pose / cost (needed by ProcessPossibleShortcut) is fetched by
@@ -710,6 +758,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			f_for[sb + rl] = fpFor;
 			myNode = -1;
 			wave_lds_sync();
+			ROWS_STAMP(7) // open-list node of the cell, prefetch, duplicate test, staging
 			// ---- insertion in child order (a_star.h:391-402 + hybrid_a_star.h:199-205): the four rows walk their
 			// children c = 0, 1, ... together
 			const int cnt = min(kRowLanes, P - base);
@@ -796,6 +845,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 					push_open(e);
 				}
 			}
+			ROWS_STAMP(8) // insertion
 			// ---- every lane writes the node record of its own child
 			if (myNode >= 0) {
 				Node nd;
@@ -816,6 +866,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				nodes[myNode] = nd;
 			}
 		}
+		ROWS_STAMP(9) // node records
 		if (capacity) {
 			status = -4;
 			finish();
@@ -1008,5 +1059,15 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				wave_lds_sync();
 			}
 		}
+		ROWS_STAMP(10) // Reeds-Shepp expansion
 	}
+#if PP_ROWS_STATS
+	if (lane == 0)
+		for (int i = 1; i < 5; i++)
+			atomicAdd(&g_rowsStats[i], statIter[i]);
+	wave_lds_sync();
+	if (lane < 14)
+		atomicAdd(&g_rowsStats[8 + lane], s_phase[lane]);
+#endif
+#undef ROWS_STAMP
 }

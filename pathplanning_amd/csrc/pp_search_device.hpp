@@ -274,6 +274,12 @@ PPD_INLINE void front_clear(FrontLane& f)
 }
 PPD_INLINE bool key_before(unsigned long long ak, unsigned int as, unsigned long long bk, unsigned int bs) { return ak < bk || (ak == bk && as < bs); }
 
+#ifndef PP_SEARCH_SETPRIO
+#define PP_SEARCH_SETPRIO 1 // search waves raise their issue priority (s_setprio 3) over the wavefront kernels' waves
+#endif
+#ifndef PP_ROWS_PRIO
+#define PP_ROWS_PRIO 1 // rows kernel: above the wavefront kernels, below the one-query-per-wave kernel (which runs the longest queries)
+#endif
 #ifndef PP_FRONT_CAP
 #define PP_FRONT_CAP 64 // entries of the open list kept in registers (tuning experiments: 16 / 32)
 #endif

@@ -158,6 +158,24 @@ def test_search_rows_are_reused_by_successive_queries(monkeypatch):
     assert [r.n_expanded for r in res2] == [r.n_expanded for r in res][::-1]
 
 
+def test_probable_longest_queries_run_one_per_wave(monkeypatch):
+    """PP_SEARCH_DIRECT=k: the first k queries of the hand-out order (ranked by the wavefront kernel) are searched by the
+    one-query-per-wave kernel on a second stream while the rows kernel works on the rest; every query must still be the
+    oracle's, whichever kernel ran it, and a second batch on the same planner must reuse the slots cleanly."""
+    monkeypatch.delenv("PP_SEARCH_ROWS", raising=False)
+    monkeypatch.setenv("PP_SEARCH_DIRECT", "12")
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    rng = np.random.RandomState(77)
+    n = 70
+    starts = valid_random_poses(rng, w, n)
+    goals = valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 4000
+    planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=8)
+    assert compare(planner, res, h, starts, goals, seeds) >= n // 2
+    res2 = planner.search_batch(starts[::-1].copy(), goals[::-1].copy(), seeds[::-1].copy())
+    assert [r.n_expanded for r in res2] == [r.n_expanded for r in res][::-1]
+
+
 def test_row_primitives_selftest():
     """DPP row shifts / butterflies / bpermute reads used by the four-queries-per-wave kernel, against scalar loops."""
     import subprocess
