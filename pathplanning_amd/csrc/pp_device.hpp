@@ -104,6 +104,29 @@ PPD_INLINE bool is_state_valid(const MapView& m, double x, double y, double thet
 	return distance >= m.minSafeRadius;
 }
 
+/// is_state_valid in two halves, so that the caller can put other work between the load and its first use (a wave
+/// stalls at the first instruction that needs a loaded value): `issue` does the bounds tests and starts the distance
+/// load, `finish` is the comparison.  Same result as is_state_valid.
+PPD_INLINE bool is_state_valid_issue(const MapView& m, double x, double y, double theta, float& rawDistance)
+{
+	const double lx = x - m.lox, ly = y - m.loy;
+	const double lt = wrap_theta(theta);
+	int row, col;
+	world_to_cell(m, x, y, row, col);
+	rawDistance = 0.0f;
+	if (lx < m.lbx || lx > m.ubx)
+		return false;
+	if (ly < m.lby || ly > m.uby)
+		return false;
+	if (lt < m.lbt || lt > m.ubt)
+		return false;
+	if (!inside_map(m, row, col))
+		return false;
+	rawDistance = m.dist[(size_t)row * m.cols + col];
+	return true;
+}
+PPD_INLINE bool is_state_valid_finish(const MapView& m, bool inBounds, float rawDistance) { return inBounds && rawDistance >= m.minSafeRadius; }
+
 /// Same test without the distance: the cell's answer comes from the validity bitmap (one bit per cell, the result of the
 /// identical float comparison), so a streamed check moves 24 B in + 1 B out and the 128 KiB bitmap stays in cache
 /// instead of a 4-byte gather that pulls a whole line of the 4 MiB distance grid per pose.
@@ -331,6 +354,35 @@ PPD_INLINE double voronoi_cost(const MapView& m, const PathT& path, float interp
 		col = min(max(col, 0), m.cols - 1);
 		voronoiCost = m.pathcost[(size_t)row * m.cols + col];
 	}
+	voronoiCost *= interpLength;
+	return voronoiCostMultiplier * (double)voronoiCost;
+}
+
+/// voronoi_cost in two halves (see is_state_valid_issue): the map read, then the arithmetic on the value.
+template <typename PathT>
+PPD_INLINE void voronoi_cost_issue(const MapView& m, const PathT& path, float interpLength, float& raw)
+{
+	raw = 0.0f;
+	const double pathLength = path.length;
+	if (0.0 < pathLength) {
+		double lastLength = 0.0;
+		if (interpLength > 0.0f)
+			for (double length = 0.0; length < pathLength; length += (double)interpLength) {
+				if (length == lastLength && length != 0.0)
+					break;
+				lastLength = length;
+			}
+		Pose p = path.interpolate(lastLength / pathLength);
+		int row, col;
+		world_to_cell(m, p.x, p.y, row, col);
+		row = min(max(row, 0), m.rows - 1);
+		col = min(max(col, 0), m.cols - 1);
+		raw = m.pathcost[(size_t)row * m.cols + col];
+	}
+}
+PPD_INLINE double voronoi_cost_finish(float raw, float interpLength, double voronoiCostMultiplier)
+{
+	float voronoiCost = raw;
 	voronoiCost *= interpLength;
 	return voronoiCostMultiplier * (double)voronoiCost;
 }

@@ -579,18 +579,24 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				bool packed = A.ks.pack(ix, iy, it, key);
 				if (packed)
 					st = keymap[key];
-				hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
+				HeurLoads hl;
+				combined_heuristic_issue(A.heur, m, field, goal, child, cs, cc, hl);
 				// Voronoi term of the full-length arc: its only map read (the last sample, Q8) is issued with the look-ups
-				const double voroFull = voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
+				float voroRaw;
+				voronoi_cost_issue(m, a, A.rp.voroDiagRes, voroRaw);
 				float lastValidRatio;
 				int checks = 0;
 				ok = true;
 				lanePathChecks++;
 				// validity / distance of the child's own pose: the first march sample of ITS children (not a counted check)
 				float cd0;
-				d0 = is_state_valid(m, child.x, child.y, child.t, cd0) ? cd0 : -1.0f;
+				const bool cIn = is_state_valid_issue(m, child.x, child.y, child.t, cd0);
 				const bool pathValid = is_path_valid_from(m, a, a.init, pDist0, lastValidRatio, checks);
 				PP_STAMP(PH_DUP); // [diagnostic: look-up issue + validity march]
+				// the values the look-ups above fetched (loaded under the march)
+				hh = combined_heuristic_finish(A.heur, hl);
+				const double voroFull = voronoi_cost_finish(voroRaw, A.rp.voroDiagRes, A.rp.voronoiMult);
+				d0 = is_state_valid_finish(m, cIn, cd0) ? cd0 : -1.0f;
 				if (!pathValid) {
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
@@ -1036,6 +1042,10 @@ struct pp_planner {
 	// the probable longest queries of a batch run one per wave next to the rows kernel (PP_SEARCH_DIRECT), on their own stream
 	hipStream_t directStream = nullptr;
 	hipEvent_t e3 = nullptr;
+	// PP_TAIL_CUS=n: the continuation of the set-aside (longest) queries runs on a stream restricted to n compute units, so the
+	// long-lived search waves stop scattering over every CU (where each one keeps a second wavefront workgroup from fitting)
+	hipStream_t tailStream = nullptr;
+	hipEvent_t eTail0 = nullptr, eTail1 = nullptr;
 	int directCount = 0;
 	float wavefrontMs = 0, searchMs = 0;
 	int lastBatch = 0;
@@ -1069,6 +1079,12 @@ void free_planner(pp_planner* p)
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
+	if (p->tailStream)
+		(void)hipStreamDestroy(p->tailStream);
+	if (p->eTail0)
+		(void)hipEventDestroy(p->eTail0);
+	if (p->eTail1)
+		(void)hipEventDestroy(p->eTail1);
 	if (p->directStream)
 		(void)hipStreamDestroy(p->directStream);
 	if (p->e3)
@@ -1320,6 +1336,15 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 			e = masked(0, nS, &p->searchStream);
 		if (e == hipSuccess && nW > 0 && nW < nCu)
 			e = masked(nCu - nW, nW, &p->wfStream);
+		const char* tc = getenv("PP_TAIL_CUS");
+		const int nT = tc && p->rowsKernel ? atoi(tc) : 0;
+		if (e == hipSuccess && nT > 0 && nT < nCu) {
+			e = masked(0, nT, &p->tailStream);
+			if (e == hipSuccess)
+				e = hipEventCreateWithFlags(&p->eTail0, hipEventDisableTiming);
+			if (e == hipSuccess)
+				e = hipEventCreateWithFlags(&p->eTail1, hipEventDisableTiming);
+		}
 	}
 	if (e != hipSuccess) {
 		free_planner(p);
@@ -1450,10 +1475,19 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 				planner->bandMeta);
 			PP_HIP_TRY(hipGetLastError());
 		}
+		hipStream_t const ts = planner->tailStream ? planner->tailStream : s;
+		if (ts != s && (secondPass || cap1 > 0)) {
+			PP_HIP_TRY(hipEventRecord(planner->eTail0, s));
+			PP_HIP_TRY(hipStreamWaitEvent(ts, planner->eTail0, 0));
+		}
 		if (secondPass || cap1 > 0) // whatever is still set aside: one wave per query (the block count is read on the device)
-			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.listCap), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
+			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.listCap), dim3(64), 0, ts, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
 				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates, planner->bands, planner->bandInvW, planner->bandMeta, nullptr, 0);
+		if (ts != s && (secondPass || cap1 > 0)) {
+			PP_HIP_TRY(hipEventRecord(planner->eTail1, ts));
+			PP_HIP_TRY(hipStreamWaitEvent(s, planner->eTail1, 0));
+		}
 	} else if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
 			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW, planner->bandMeta, nullptr, 0);

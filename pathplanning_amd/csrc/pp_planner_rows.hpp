@@ -667,10 +667,12 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				bool packed = A.ks.pack(ix, iy, it, key);
 				if (packed)
 					st = keymap[key];
-				hh = combined_heuristic_sc(A.heur, m, field, goal, child, cs, cc);
+				HeurLoads hl;
+				combined_heuristic_issue(A.heur, m, field, goal, child, cs, cc, hl);
 				ROWS_STAMP(12) // key map + heuristics
 				// Voronoi term of the full-length arc: its only map read (the last sample, Q8) is issued with the look-ups
-				const double voroFull = voronoi_cost(m, a, A.rp.voroDiagRes, A.rp.voronoiMult);
+				float voroRaw;
+				voronoi_cost_issue(m, a, A.rp.voroDiagRes, voroRaw);
 				ROWS_STAMP(13) // Voronoi term
 				float lastValidRatio;
 				int checks = 0;
@@ -678,10 +680,14 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 				lanePathChecks++;
 				// validity / distance of the child's own pose: the first march sample of ITS children (not a counted check)
 				float cd0;
-				d0 = is_state_valid(m, child.x, child.y, child.t, cd0) ? cd0 : -1.0f;
+				const bool cIn = is_state_valid_issue(m, child.x, child.y, child.t, cd0);
 				ROWS_STAMP(4) // child's own validity
 				const bool pathValid = is_path_valid_from(m, a, a.init, pDist0, lastValidRatio, checks);
 				ROWS_STAMP(5) // validity march
+				// the values the look-ups above fetched (loaded under the march)
+				hh = combined_heuristic_finish(A.heur, hl);
+				const double voroFull = voronoi_cost_finish(voroRaw, A.rp.voroDiagRes, A.rp.voronoiMult);
+				d0 = is_state_valid_finish(m, cIn, cd0) ? cd0 : -1.0f;
 				if (!pathValid) {
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 					child = a.interpolate_sc((double)lastValidRatio, cs, cc);

@@ -96,6 +96,85 @@ PPD_INLINE double obstacle_heuristic(const HeurView& h, const MapView& m, const 
 	return heuristic < euclidean ? euclidean : heuristic; // std::max(heuristic, euclidean)
 }
 
+/// combined_heuristic_sc in two halves: `issue` computes the indices and starts the two table reads (non-holonomic
+/// table, obstacle field), `finish` does the arithmetic on the loaded values -- the caller runs the validity march in
+/// between, so the reads overlap it instead of stalling the wave one after the other.  Same value as
+/// combined_heuristic_sc.
+struct HeurLoads {
+	double aRaw;    // non-holonomic table entry (when aFromTable)
+	double aConst;  // value that needs no read: outside the table, or one of the k < 0 cases
+	float cRaw;     // obstacle field entry (when cInside)
+	double euclid;
+	bool aFromTable, cInside;
+};
+PPD_INLINE void combined_heuristic_issue(const HeurView& h, const MapView& m, const float* field, const Pose& goal, const Pose& state, double sinS, double cosS, HeurLoads& L)
+{
+	const double dx = goal.x - state.x, dy = goal.y - state.y;
+	L.aFromTable = false;
+	L.aConst = 0.0;
+	L.aRaw = 0.0;
+	{ // nonholo_heuristic_sc
+		const double s = -sinS, c = cosS;
+		Pose delta;
+		delta.x = c * dx + (-s) * dy;
+		delta.y = s * dx + c * dy;
+		delta.t = wrap_theta(wrap_theta(goal.t - state.t));
+		int i = trunc_to_int(round((delta.x + h.offX) / h.spatialRes));
+		int j = trunc_to_int(round((delta.y + h.offY) / h.spatialRes));
+		int k = trunc_to_int(round(delta.t / h.angularRes));
+		if (k == h.na)
+			k = 0;
+		if (i < 0 || i >= h.nx || j < 0 || j >= h.ny) {
+			double euclideanDistance = sqrt(delta.x * delta.x + delta.y * delta.y);
+			L.aConst = h.minMult * euclideanDistance;
+		} else {
+			// nonholo_lookup
+			const size_t na = (size_t)h.na;
+			const double* p = nullptr;
+			if (k >= 0)
+				p = &h.table[((size_t)i * h.ny + j) * na + k];
+			else if (!h.negativeKRead)
+				p = &h.table[((size_t)i * h.ny + j) * na + (k + h.na)];
+			else {
+				const unsigned long long chunk = ((unsigned long long)(na * 8 + 8 + 15) / 16) * 16;
+				if (k == -1)
+					L.aConst = __longlong_as_double((long long)(chunk | 1ull));
+				else if (j >= 1) {
+					const int kk = (int)(chunk / 8) + k;
+					if (kk >= 0 && kk < h.na)
+						p = &h.table[((size_t)i * h.ny + (j - 1)) * na + kk];
+				}
+			}
+			if (p) {
+				L.aRaw = *p;
+				L.aFromTable = true;
+			}
+		}
+	}
+	{ // obstacle_heuristic
+		L.euclid = sqrt(dx * dx + dy * dy);
+		int row, col;
+		world_to_cell(m, state.x, state.y, row, col);
+		L.cInside = inside_map(m, row, col);
+		L.cRaw = 0.0f;
+		if (L.cInside)
+			L.cRaw = field[field_tiled_index(m.cols, row, col)];
+	}
+}
+PPD_INLINE double combined_heuristic_finish(const HeurView& h, const HeurLoads& L)
+{
+	double value = -__builtin_huge_val();
+	const double a = L.aFromTable ? L.aRaw : L.aConst;
+	value = value < a ? a : value;
+	double b = L.euclid;
+	if (L.cInside && !(L.cRaw == __builtin_huge_valf())) {
+		const double heuristic = (double)(L.cRaw * h.obstCostMult - h.obstDiagRes);
+		b = heuristic < L.euclid ? L.euclid : heuristic;
+	}
+	value = value < b ? b : value;
+	return value;
+}
+
 /// AStarCombinedHeuristic::GetHeuristicValue, algo/a_star.h:102-109
 PPD_INLINE double combined_heuristic(const HeurView& h, const MapView& m, const float* field, const Pose& goal, const Pose& state)
 {
