@@ -765,8 +765,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 			myNode = -1;
 			wave_lds_sync();
 			ROWS_STAMP(7) // open-list node of the cell, prefetch, duplicate test, staging
-			// ---- insertion in child order (a_star.h:391-402 + hybrid_a_star.h:199-205): the four rows walk their
-			// children c = 0, 1, ... together
+			// ---- insertion in child order (a_star.h:391-402 + hybrid_a_star.h:199-205)
 			const int cnt = min(kRowLanes, P - base);
 			// Most children change nothing (their cell is explored, or holds an open-list node they do not beat): every
 			// lane settles that for its own child, and only the children that push, replace, share a cell with an
@@ -784,14 +783,14 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 					}
 				}
 			}
-			const unsigned long long needAll = __ballot(need);
-			const uint32_t rowNeed = row_bits(needAll, lane);
-			uint32_t todo = (uint32_t)(needAll | (needAll >> 16) | (needAll >> 32) | (needAll >> 48)) & 0xFFFFu; // children some row must walk
-			todo = (uint32_t)__builtin_amdgcn_readfirstlane((int)todo);
-			for (; todo; todo &= todo - 1u) {
+			// every row walks ITS OWN list of such children, the rows side by side: pass j handles the j-th listed child of
+			// each row (the passes of a wave = the longest list, not the union of the lists)
+			uint32_t todo = row_bits(__ballot(need), lane);
+			while (todo != 0u) { // row-uniform condition: a row leaves when its list is done
 				const int c = __ffs((int)todo) - 1;
+				todo &= todo - 1u;
 				const uint32_t flags = c_flags[sb + c];
-				if (!((rowNeed >> c) & 1u) || !(flags & 1u) || capacity)
+				if (!(flags & 1u) || capacity)
 					continue;
 				const uint32_t ckey = c_key[sb + c];
 				uint32_t cst = c_state[sb + c];
