@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=192, help="queries timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--search-rows", type=int, default=8192, help="search rows shared by the batches in flight (8192 = every resident wave slot)")
-    ap.add_argument("--debug-skip", type=int, default=0, choices=(0, 1, 2),
+    ap.add_argument("--debug-skip", type=int, default=0, choices=(0, 1, 2, 3),
                     help="timing experiments only (the line is then marked invalid): after the warm-up drop the wavefront (1) or the search (2) from every step; "
                          "with 1 the searches reuse the cost fields the warm-up left in each lane (same goals every step)")
     ap.add_argument("--streams", type=int, default=8, help="independent batches kept in flight (one planner + HIP stream each)")

@@ -1423,7 +1423,7 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	static const bool lpt = !(getenv("PP_SEARCH_ORDER") && getenv("PP_SEARCH_ORDER")[0] == '0');
 	const bool ordered = planner->rowsKernel && lpt && n_queries <= 4096 && n_queries > planner->searchRows;
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
-	const char* const dbgEnv = getenv("PP_DEBUG_SKIP"); // timing experiments only (bench.py --debug-skip): 1 = no wavefront, 2 = no search
+	const char* const dbgEnv = getenv("PP_DEBUG_SKIP"); // timing experiments only (bench.py --debug-skip): 1 = no wavefront, 2 = no search, 3 = set-aside queries are dropped
 	const int dbgSkip = dbgEnv ? atoi(dbgEnv) : 0;
 	hipStream_t const ws = planner->wfStream ? planner->wfStream : s;
 	if (ws != s)
@@ -1480,7 +1480,7 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 			PP_HIP_TRY(hipEventRecord(planner->eTail0, s));
 			PP_HIP_TRY(hipStreamWaitEvent(ts, planner->eTail0, 0));
 		}
-		if (secondPass || cap1 > 0) // whatever is still set aside: one wave per query (the block count is read on the device)
+		if ((secondPass || cap1 > 0) && dbgSkip != 3) // whatever is still set aside: one wave per query (the block count is read on the device)
 			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.listCap), dim3(64), 0, ts, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
 				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates, planner->bands, planner->bandInvW, planner->bandMeta, nullptr, 0);
