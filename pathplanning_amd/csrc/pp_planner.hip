@@ -105,6 +105,7 @@ struct SearchArgs {
 	int extraSlots;    // buffer slots beyond the rows' own, taken by rows whose query was set aside
 	int searchRows;    // rows the planner's buffers were sized for (spare slots start here)
 	int listCap;       // capacity of each SuspendRec list: one record per spare slot + one per row
+	int rowsWaves;     // rows kernel: waves of this launch (the grid is rounded up to whole workgroups)
 	int directCount;   // rows kernel: the first `directCount` queries of the hand-out order are not its own (they run one per wave)
 	size_t cells;
 	int64_t fieldElems; // floats per query in costFields (8 x 8-tiled obstacle-heuristic field)
@@ -1227,8 +1228,8 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		hipDeviceProp_t prop;
 		p->searchWaves = 2048;
 		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_hybrid_search_rows, 64, 0) == hipSuccess && perCu >= 1)
-			p->searchWaves = perCu * prop.multiProcessorCount;
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_hybrid_search_rows, 64 * PP_ROWS_WAVES_PER_WG, 0) == hipSuccess && perCu >= 1)
+			p->searchWaves = perCu * PP_ROWS_WAVES_PER_WG * prop.multiProcessorCount;
 		// Which search kernel?  The four-queries-per-wave kernel (pp_planner_rows.hpp) issues ~4x fewer instructions per
 		// expansion and needs node/heap/key-map buffers only for its resident rows, so many batches fit in HBM at once;
 		// the one-query-per-wave kernel advances a single query ~1.4x faster.  Throughput-sized planners take the
@@ -1460,7 +1461,9 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		SuspendRec* const list1 = planner->suspended;
 		SuspendRec* const list2 = planner->suspended + planner->args.listCap;
 		const int cap1 = planner->args.suspendAfter, cap2 = planner->args.suspendAfter2, cpt = planner->compactBelow;
-		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(grid), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
+		constexpr int kWg = PP_ROWS_WAVES_PER_WG;
+		planner->args.rowsWaves = grid;
+		hipLaunchKernelGGL(k_hybrid_search_rows, dim3((grid + kWg - 1) / kWg), dim3(64 * kWg), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
 			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, ctl, list1,
 			ordered ? planner->order : nullptr, cap1, nullptr, nullptr, ctl + 1, spare, cpt, planner->bands, planner->bandInvW, planner->bandMeta);
 		PP_HIP_TRY(hipGetLastError());
@@ -1469,7 +1472,8 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 			// second pass of the rows kernel over list 1 (its length is read on the device); it ends waves with a single
 			// busy row, and the one-query-per-wave kernel finishes those
 			const int waves2 = (planner->args.listCap + kRowsPerWave - 1) / kRowsPerWave;
-			hipLaunchKernelGGL(k_hybrid_search_rows, dim3(waves2 < wavesMax ? waves2 : wavesMax), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
+			planner->args.rowsWaves = waves2 < wavesMax ? waves2 : wavesMax;
+			hipLaunchKernelGGL(k_hybrid_search_rows, dim3((planner->args.rowsWaves + kWg - 1) / kWg), dim3(64 * kWg), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates,
 				planner->results, ctl + 2, list2, nullptr, cap2 > cap1 ? cap2 : 0, list1, ctl + 1, ctl + 3, spare, cpt > 0 ? 1 : 0, planner->bands, planner->bandInvW,
 				planner->bandMeta);

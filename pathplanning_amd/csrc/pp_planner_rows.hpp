@@ -25,12 +25,19 @@
 #if PP_ROWS_STATS
 __device__ unsigned long long g_rowsStats[24];
 #endif
+#ifndef PP_ROWS_WAVES_PER_WG
+#define PP_ROWS_WAVES_PER_WG 4
+#endif
+#if PP_ROWS_STATS
+#undef PP_ROWS_WAVES_PER_WG
+#define PP_ROWS_WAVES_PER_WG 1 // the statistics build keeps wave-level sums in workgroup-shared words
+#endif
 #ifndef PP_ROWS_EAGER_REFILL
 #define PP_ROWS_EAGER_REFILL 1
 #endif
 
 // --------------------------------------------------------------------------------------------------- kernel --
-__global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_rows(SearchArgs A, int nQueries, const double* __restrict__ starts,
+__global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_rows(SearchArgs A, int nQueries, const double* __restrict__ starts,
 	const double* __restrict__ goals, const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase,
 	HeapEntry* __restrict__ heapBase, uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase,
 	PathRec* __restrict__ pathBase, unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery,
@@ -48,13 +55,21 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	// the SIMDs with are throughput work: search waves issue first
 	__builtin_amdgcn_s_setprio(PP_ROWS_PRIO);
 #endif
-	const int lane = threadIdx.x;
+	// The waves of a workgroup are independent (no workgroup barrier anywhere below); they are launched together only so
+	// that they land on ONE compute unit: with the longest-first hand-out order the first waves hold the longest queries,
+	// and the long-lived waves of a batch then sit on few CUs instead of one CU each (every CU that hosts a search wave
+	// has room for only one of the two wavefront workgroups it could run).
+	constexpr int kW = PP_ROWS_WAVES_PER_WG;
+	const int lane = threadIdx.x & 63;
+	const int waveIdx = (int)blockIdx.x * kW + (int)(threadIdx.x >> 6);
+	if (waveIdx >= A.rowsWaves)
+		return;
 	const int rl = lane & (kRowLanes - 1);
 	const int sb = (lane >> 4) * kRowSlots; // first staging slot of this row
 	// search buffers (node records, heap, key map, engine state) belong to the ROW, not to the query: the row's
 	// queries use them one after the other, so a planner needs them for its resident rows only
 	// (a row that hands its query over to the one-query-per-wave kernel leaves the slot to it and takes a spare one)
-	size_t slot = (size_t)blockIdx.x * kRowsPerWave + (size_t)(lane >> 4);
+	size_t slot = (size_t)waveIdx * kRowsPerWave + (size_t)(lane >> 4);
 	Node* nodes = nodesBase + slot * A.maxNodes;
 	HeapEntry* heap = heapBase + slot * A.maxNodes;
 	uint32_t* keymap = keymapBase + slot * A.ks.size();
@@ -66,18 +81,30 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_
 	// staging of the children of the node being expanded (per row); kept until the next expansion so that a child popped
 	// right away is read back from LDS instead of HBM
 	constexpr int kS = kRowsPerWave * kRowSlots;
-	__shared__ double c_x[kS], c_y[kS], c_t[kS], c_cost[kS], c_total[kS], c_len[kS], c_h[kS], c_sin[kS], c_cos[kS];
-	__shared__ double f_x[kS], f_y[kS], f_t[kS], f_tot[kS]; // open-list node already in the child's cell (shortcut test)
-	__shared__ uint32_t c_key[kS], c_state[kS], f_for[kS];
-	__shared__ float c_d0[kS]; // obstacle distance at the child's pose (< 0: invalid state), see Node::dist0
-	__shared__ uint8_t c_flags[kS], c_valid[kS]; // flags: 1 = valid child, 2 = an earlier child of the batch shares its cell
-	__shared__ int16_t c_action[kS];
-	__shared__ int s_rsChecks[kRowsPerWave];
-	__shared__ HeapEntry s_spill[kRowsPerWave][kRowLanes];
-	HeapEntry* const spillBuf = s_spill[lane >> 4];
-	// f-bands of the open list (pp_search_device.hpp): entries per ring slot, four u8 counters per word
-	__shared__ __attribute__((aligned(16))) uint32_t s_bandCnt[kRowsPerWave][kBands / 4];
-	uint32_t* const bandCnt = s_bandCnt[lane >> 4];
+	struct WaveLds {
+		double c_x[kS], c_y[kS], c_t[kS], c_cost[kS], c_total[kS], c_len[kS], c_h[kS], c_sin[kS], c_cos[kS];
+		double f_x[kS], f_y[kS], f_t[kS], f_tot[kS]; // open-list node already in the child's cell (shortcut test)
+		HeapEntry spill[kRowsPerWave][kRowLanes];
+		// f-bands of the open list (pp_search_device.hpp): entries per ring slot, four u8 counters per word
+		uint32_t bandCnt[kRowsPerWave][kBands / 4];
+		uint32_t c_key[kS], c_state[kS], f_for[kS];
+		float c_d0[kS]; // obstacle distance at the child's pose (< 0: invalid state), see Node::dist0
+		int rsChecks[kRowsPerWave];
+		int16_t c_action[kS];
+		uint8_t c_flags[kS], c_valid[kS]; // flags: 1 = valid child, 2 = an earlier child of the batch shares its cell
+	};
+	static_assert(offsetof(WaveLds, bandCnt) % 16 == 0 && sizeof(WaveLds) % 16 == 0, "band counters are copied as uint4");
+	__shared__ __attribute__((aligned(16))) WaveLds s_wave[kW];
+	WaveLds& W = s_wave[threadIdx.x >> 6];
+	double *const c_x = W.c_x, *const c_y = W.c_y, *const c_t = W.c_t, *const c_cost = W.c_cost, *const c_total = W.c_total, *const c_len = W.c_len, *const c_h = W.c_h,
+		   *const c_sin = W.c_sin, *const c_cos = W.c_cos, *const f_x = W.f_x, *const f_y = W.f_y, *const f_t = W.f_t, *const f_tot = W.f_tot;
+	uint32_t *const c_key = W.c_key, *const c_state = W.c_state, *const f_for = W.f_for;
+	float* const c_d0 = W.c_d0;
+	uint8_t *const c_flags = W.c_flags, *const c_valid = W.c_valid;
+	int16_t* const c_action = W.c_action;
+	int* const s_rsChecks = W.rsChecks;
+	HeapEntry* const spillBuf = W.spill[lane >> 4];
+	uint32_t* const bandCnt = W.bandCnt[lane >> 4];
 
 	const MapView& m = A.m;
 	const int P = A.prims.n;
