@@ -62,6 +62,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PPError("libpphip.so not found at %s -- build it with `python -m pathplanning_amd.build` (hipcc, gfx950). "
                       "There is no CPU fallback." % LIB_PATH)
+    try:
+        # PyTorch ships its own copy of the HIP / HSA runtime.  Whichever copy initialises second in a process sees no
+        # device, so when torch is installed it goes first and libpphip binds to the copy torch loaded.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.pp_last_error.restype = C.c_char_p
     L.pp_obstacle_heuristic_workspace_bytes.restype = C.c_int64
