@@ -28,6 +28,7 @@ ppd::MapView pp_map::view() const
 	v.rows = desc.rows;
 	v.cols = desc.cols;
 	v.res = desc.resolution;
+	v.invRes = 1.0 / (double)desc.resolution;
 	v.gx = desc.grid_origin[0];
 	v.gy = desc.grid_origin[1];
 	v.lox = desc.local_origin[0];
@@ -444,6 +445,7 @@ static int make_rollout(pp_map* map, const pp_hybrid_params* params, int32_t n_p
 	rp.arcLength = params->spatial_resolution * 1.5; // hybrid_a_star.cpp:115
 	rp.spatialRes = params->spatial_resolution;
 	rp.angularRes = params->angular_resolution;
+	rp.lat.set(params->spatial_resolution, params->angular_resolution);
 	rp.forwardMult = params->forward_cost_multiplier;
 	rp.reverseMult = params->reverse_cost_multiplier;
 	rp.voronoiMult = params->voronoi_cost_multiplier;

@@ -32,9 +32,22 @@ struct Pose {
 };
 
 /// Device view of one map set (filled by pp_map_*).
+/// lattice resolutions with their correctly rounded reciprocals (see div_by)
+struct Resolutions {
+	double spatial, angular, invSpatial, invAngular;
+	__host__ __device__ void set(double s, double a)
+	{
+		spatial = s;
+		angular = a;
+		invSpatial = 1.0 / s;
+		invAngular = 1.0 / a;
+	}
+};
+
 struct MapView {
 	int rows, cols;
 	float res;              // OccupancyMap::resolution
+	double invRes;          // 1.0 / (double)res, correctly rounded on the host (div_by)
 	double gx, gy;          // m_worldGridOrigin
 	double lox, loy;        // m_localOrigin
 	double lbx, lby, lbt;   // StateSpaceSE2 bounds
@@ -46,6 +59,19 @@ struct MapView {
 	const uint8_t* occ8;    // 1 = occupied
 	const uint32_t* validBits; // bit (row * cols + col): dist >= minSafeRadius, rebuilt when either changes (128 KiB at 1024^2)
 };
+
+/// a / b for a divisor whose correctly rounded reciprocal y = 1.0 / b is known (resolutions: wave-uniform kernel
+/// arguments): product, exact residual (one fma), correction (one fma) -- Markstein's sequence, which returns the
+/// correctly rounded quotient, i.e. the bits of `a / b`, for every finite a.  It replaces the ~12-instruction IEEE
+/// division (quarter-rate v_rcp_f64 + Newton + v_div_fixup) on the per-pose paths.  Non-finite a gives NaN where a / b
+/// gives +-inf; every caller converts with trunc_to_int, which maps both to INT_MIN.  Checked against `a / b` on the host for
+/// 2.7e9 operands including +-4 ulp neighbourhoods of exact multiples (tests/cpp/test_reciprocal_division.c, run by the CPU suite).
+PPD_INLINE double div_by(double a, double b, double y)
+{
+	const double q0 = a * y;
+	const double e = fma(-q0, b, a);
+	return fma(e, y, q0);
+}
 
 /// geometry/2dplane.h:36-45
 PPD_INLINE double wrap_theta(double theta)
@@ -74,8 +100,8 @@ PPD_INLINE int trunc_to_int(double v)
 /// OccupancyMap::WorldPositionToGridCell(bounded = false), occupancy_map.h:106-117,180-183
 PPD_INLINE void world_to_cell(const MapView& m, double x, double y, int& row, int& col)
 {
-	row = trunc_to_int((x - m.gx) / (double)m.res);
-	col = trunc_to_int((y - m.gy) / (double)m.res);
+	row = trunc_to_int(div_by(x - m.gx, (double)m.res, m.invRes));
+	col = trunc_to_int(div_by(y - m.gy, (double)m.res, m.invRes));
 }
 
 PPD_INLINE bool inside_map(const MapView& m, int row, int col)
@@ -400,11 +426,11 @@ PPD_INLINE int alias_heading_bin(int theta)
 }
 
 /// HybridAStar::StatePropagator::DiscretizePose, algo/hybrid_a_star.h:104-111
-PPD_INLINE void discretize_pose(const Pose& p, double spatialRes, double angularRes, int headingAlias, int& ix, int& iy, int& it)
+PPD_INLINE void discretize_pose(const Pose& p, const Resolutions& r, int headingAlias, int& ix, int& iy, int& it)
 {
-	ix = trunc_to_int(p.x / spatialRes);
-	iy = trunc_to_int(p.y / spatialRes);
-	it = trunc_to_int(wrap_theta(p.t) / angularRes);
+	ix = trunc_to_int(div_by(p.x, r.spatial, r.invSpatial));
+	iy = trunc_to_int(div_by(p.y, r.spatial, r.invSpatial));
+	it = trunc_to_int(div_by(wrap_theta(p.t), r.angular, r.invAngular));
 	if (headingAlias)
 		it = alias_heading_bin(it);
 }

@@ -31,6 +31,7 @@ struct PrimTable {
 struct RolloutParams {
 	double arcLength;        // 1.5 * spatialResolution (hybrid_a_star.cpp:115)
 	double spatialRes, angularRes;
+	ppd::Resolutions lat;    // the same two with their reciprocals (discretize_pose)
 	double forwardMult, reverseMult, voronoiMult;
 	float voroDiagRes;       // (float)(resolution * sqrt(2.0)), hybrid_a_star.cpp:38
 	int headingAlias;

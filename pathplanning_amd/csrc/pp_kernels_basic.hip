@@ -44,6 +44,9 @@ __global__ void k_occ_to_u8(const int32_t* __restrict__ occ, uint8_t* __restrict
 // One pose per thread.  A block stages its 256 poses (6 KiB, contiguous in the
 // Pose2d AoS layout) through LDS with 16-byte coalesced loads, so HBM sees whole
 // lines once; the distance grid is a cached gather (4 MiB at 1024^2: L2 resident).
+#ifndef PP_CS_GRID_PER_CU
+#define PP_CS_GRID_PER_CU 16 // workgroups per CU of the grid-stride launch
+#endif
 #ifndef PP_CS_PER
 #define PP_CS_PER 4
 #endif
@@ -179,10 +182,10 @@ __global__ void __launch_bounds__(kBlock) k_rollout(MapView m, pph::RolloutParam
 		a.length = rp.arcLength;
 		a.backward = prims.backward[prim];
 		int pix, piy, pit;
-		discretize_pose(a.init, rp.spatialRes, rp.angularRes, rp.headingAlias, pix, piy, pit);
+		discretize_pose(a.init, rp.lat, rp.headingAlias, pix, piy, pit);
 		Pose child = a.interpolate(1.0);
 		int ix, iy, it;
-		discretize_pose(child, rp.spatialRes, rp.angularRes, rp.headingAlias, ix, iy, it);
+		discretize_pose(child, rp.lat, rp.headingAlias, ix, iy, it);
 		float lastValidRatio;
 		int checks = 0;
 		bool ok = true;
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(kBlock) k_rollout(MapView m, pph::RolloutParam
 			// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 			child = a.interpolate((double)lastValidRatio);
 			a.length *= (double)lastValidRatio;
-			discretize_pose(child, rp.spatialRes, rp.angularRes, rp.headingAlias, ix, iy, it);
+			discretize_pose(child, rp.lat, rp.headingAlias, ix, iy, it);
 			if (ix == pix && iy == piy && it == pit)
 				ok = false;
 		}
@@ -339,7 +342,7 @@ hipError_t launch_check_states(hipStream_t s, const MapView& m, int64_t n, const
 {
 	if (n <= 0)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_check_states, dim3(grid_for(n, kBlock * kCsPer, 256 * 16)), dim3(kBlock), 0, s, m, n, poses, valid, (int)((((uintptr_t)poses) & 15) == 0));
+	hipLaunchKernelGGL(k_check_states, dim3(grid_for(n, kBlock * kCsPer, 256 * PP_CS_GRID_PER_CU)), dim3(kBlock), 0, s, m, n, poses, valid, (int)((((uintptr_t)poses) & 15) == 0));
 	return hipGetLastError();
 }
 hipError_t launch_valid_bits(hipStream_t s, const float* dist, int64_t cells, float minSafeRadius, uint32_t* bits)

@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		double rs_, rc_;
 		sincos(start.t, &rs_, &rc_);
 		int ix, iy, it;
-		discretize_pose(start, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+		discretize_pose(start, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 		uint32_t key = kNoKey;
 		const bool ok = A.ks.pack(ix, iy, it, key);
 		if (lane == 0) {
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		rsNode = -1;
 		nExpanded++;
 		int pix, piy, pit;
-		discretize_pose(ppose, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, pix, piy, pit);
+		discretize_pose(ppose, A.rp.lat, A.rp.headingAlias, pix, piy, pit);
 		PP_STAMP(PH_LOAD);
 		// RS gate input (hybrid_a_star.cpp:81): the heuristic of this pose was computed when the node was created
 		const double hCost = pH;
@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				a.backward = A.prims.backward[p];
 				child = a.interpolate_sc(1.0, cs, cc);
 				int ix, iy, it;
-				discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+				discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 				PP_STAMP(PH_HEUR); // [diagnostic: endpoint]
 				// look-ups of the full-length child are issued before the validity march so that their
 				// latency overlaps it (they are redone only when the arc gets truncated)
@@ -602,7 +602,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
 					a.length *= (double)lastValidRatio;
-					discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+					discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 					if (ix == pix && iy == piy && it == pit)
 						ok = false;
 					else {
@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
 						const Pose child = path.interpolate(1.0);
 						int ix, iy, it;
-						discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+						discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 						const double voro = voronoi_cost(m, path, A.rp.voroDiagRes, A.rp.voronoiMult);
 						const double cost = pathAndSwitchingCosts + voro;
 						uint32_t key;
@@ -1165,6 +1165,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	A.rp.arcLength = params->spatial_resolution * 1.5;
 	A.rp.spatialRes = params->spatial_resolution;
 	A.rp.angularRes = params->angular_resolution;
+	A.rp.lat.set(params->spatial_resolution, params->angular_resolution);
 	A.rp.forwardMult = params->forward_cost_multiplier;
 	A.rp.reverseMult = params->reverse_cost_multiplier;
 	A.rp.voronoiMult = params->voronoi_cost_multiplier;
@@ -1181,6 +1182,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	A.heur.na = dims[2];
 	A.heur.spatialRes = params->spatial_resolution;
 	A.heur.angularRes = params->angular_resolution;
+	A.heur.lat.set(params->spatial_resolution, params->angular_resolution);
 	A.heur.offX = offs[0];
 	A.heur.offY = offs[1];
 	A.heur.minMult = std::min(params->reverse_cost_multiplier, params->forward_cost_multiplier);

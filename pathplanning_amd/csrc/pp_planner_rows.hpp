@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				double rs_, rc_;
 				sincos(start.t, &rs_, &rc_);
 				int ix, iy, it;
-				discretize_pose(start, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+				discretize_pose(start, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 				uint32_t key = kNoKey;
 				const bool ok = A.ks.pack(ix, iy, it, key);
 				if (rl == 0) {
@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		rsNode = -1;
 		nExpanded++;
 		int pix, piy, pit;
-		discretize_pose(ppose, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, pix, piy, pit);
+		discretize_pose(ppose, A.rp.lat, A.rp.headingAlias, pix, piy, pit);
 		const double hCost = pH; // RS gate input (hybrid_a_star.cpp:81): computed when the node was created
 		// the raw 64-bit draw the RS gate may need is fetched now (one word of the query's engine state in HBM)
 		unsigned long long mtRaw = 0ull;
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				a.backward = A.prims.backward[p];
 				child = a.interpolate_sc(1.0, cs, cc);
 				int ix, iy, it;
-				discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+				discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 				ROWS_STAMP(11) // endpoint
 				// look-ups of the full-length child are issued before the validity march so that their latency
 				// overlaps it (they are redone only when the arc gets truncated)
@@ -719,7 +719,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
 					a.length *= (double)lastValidRatio;
-					discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+					discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 					if (ix == pix && iy == piy && it == pit)
 						ok = false;
 					else {
@@ -980,7 +980,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
 						const Pose child = path.interpolate(1.0);
 						int ix, iy, it;
-						discretize_pose(child, A.rp.spatialRes, A.rp.angularRes, A.rp.headingAlias, ix, iy, it);
+						discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 						const double voro = voronoi_cost(m, path, A.rp.voroDiagRes, A.rp.voronoiMult);
 						const double cost = pathAndSwitchingCosts + voro;
 						uint32_t key;

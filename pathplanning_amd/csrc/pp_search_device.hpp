@@ -11,6 +11,7 @@ struct HeurView {
 	// NonHolonomicHeuristic (algo/heuristics.cpp:7-95)
 	int nx, ny, na;
 	double spatialRes, angularRes, offX, offY, minMult;
+	Resolutions lat; // spatialRes / angularRes with their reciprocals (div_by)
 	const double* table; // [(i*ny + j)*na + k]
 	int negativeKRead;
 	// ObstaclesHeuristic (algo/heuristics.cpp:97-166)
@@ -45,9 +46,9 @@ PPD_INLINE double nonholo_lookup(const HeurView& h, int i, int j, int k)
 PPD_INLINE double nonholo_heuristic(const HeurView& h, const Pose& goal, const Pose& state)
 {
 	Pose delta = rs::between(goal, state);
-	int i = trunc_to_int(round((delta.x + h.offX) / h.spatialRes));
-	int j = trunc_to_int(round((delta.y + h.offY) / h.spatialRes));
-	int k = trunc_to_int(round(delta.t / h.angularRes));
+	int i = trunc_to_int(round(div_by(delta.x + h.offX, h.lat.spatial, h.lat.invSpatial)));
+	int j = trunc_to_int(round(div_by(delta.y + h.offY, h.lat.spatial, h.lat.invSpatial)));
+	int k = trunc_to_int(round(div_by(delta.t, h.lat.angular, h.lat.invAngular)));
 	if (k == h.na)
 		k = 0;
 	if (i < 0 || i >= h.nx || j < 0 || j >= h.ny) {
@@ -67,9 +68,9 @@ PPD_INLINE double nonholo_heuristic_sc(const HeurView& h, const Pose& goal, cons
 	delta.x = c * dx + (-s) * dy;
 	delta.y = s * dx + c * dy;
 	delta.t = wrap_theta(wrap_theta(goal.t - state.t));
-	int i = trunc_to_int(round((delta.x + h.offX) / h.spatialRes));
-	int j = trunc_to_int(round((delta.y + h.offY) / h.spatialRes));
-	int k = trunc_to_int(round(delta.t / h.angularRes));
+	int i = trunc_to_int(round(div_by(delta.x + h.offX, h.lat.spatial, h.lat.invSpatial)));
+	int j = trunc_to_int(round(div_by(delta.y + h.offY, h.lat.spatial, h.lat.invSpatial)));
+	int k = trunc_to_int(round(div_by(delta.t, h.lat.angular, h.lat.invAngular)));
 	if (k == h.na)
 		k = 0;
 	if (i < 0 || i >= h.nx || j < 0 || j >= h.ny) {
@@ -119,9 +120,9 @@ PPD_INLINE void combined_heuristic_issue(const HeurView& h, const MapView& m, co
 		delta.x = c * dx + (-s) * dy;
 		delta.y = s * dx + c * dy;
 		delta.t = wrap_theta(wrap_theta(goal.t - state.t));
-		int i = trunc_to_int(round((delta.x + h.offX) / h.spatialRes));
-		int j = trunc_to_int(round((delta.y + h.offY) / h.spatialRes));
-		int k = trunc_to_int(round(delta.t / h.angularRes));
+		int i = trunc_to_int(round(div_by(delta.x + h.offX, h.lat.spatial, h.lat.invSpatial)));
+		int j = trunc_to_int(round(div_by(delta.y + h.offY, h.lat.spatial, h.lat.invSpatial)));
+		int k = trunc_to_int(round(div_by(delta.t, h.lat.angular, h.lat.invAngular)));
 		if (k == h.na)
 			k = 0;
 		if (i < 0 || i >= h.nx || j < 0 || j >= h.ny) {

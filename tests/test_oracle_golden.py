@@ -186,3 +186,17 @@ def test_smoke_grid_astar_example_layout():
     # Appendix A Q16: the bidirectional path repeats the meeting cell
     dup = sum(1 for i in range(1, len(rb["path"])) if tuple(rb["path"][i]) == tuple(rb["path"][i - 1]))
     assert dup == 1
+
+
+def test_reciprocal_division_is_the_ieee_quotient(tmp_path):
+    """pp_device.hpp divides by the (wave-uniform) resolutions with a product, an exact residual and a correction instead of
+    the IEEE division sequence; the result must be the bits of a / b.  Host check with the same three operations (hardware fma)."""
+    import shutil
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_reciprocal_division.c")
+    exe = str(tmp_path / "test_reciprocal_division")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    assert cc, "no C compiler"
+    subprocess.check_call([cc, "-O2", "-mfma", "-ffp-contract=off", src, "-o", exe, "-lm"])
+    out = subprocess.run([exe, "4000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
