@@ -454,6 +454,7 @@ static int make_rollout(pp_map* map, const pp_hybrid_params* params, int32_t n_p
 	pt.n = n_primitives;
 	for (int i = 0; i < n_primitives; i++) {
 		pt.kappa[i] = curvature_host[i];
+		pt.invKappa[i] = curvature_host[i] != 0.0 ? 1 / curvature_host[i] : 0.0;
 		pt.backward[i] = direction_host[i] == 1;
 	}
 	return PP_OK;

@@ -213,6 +213,7 @@ struct ArcSC {
 	Pose init;
 	double sinF, cosF;
 	double kappa;
+	double invKappa; // 1 / kappa, divided once per primitive on the host (PrimTable)
 	double length;
 	int backward;
 	PPD_INLINE Pose interpolate_sc(double ratio, double& s, double& c) const
@@ -228,8 +229,8 @@ struct ArcSC {
 		if (fabs(kappa) > 1e-9) {
 			to.t += d * kappa;
 			sincos(to.t, &s, &c);
-			to.x += 1 / kappa * (s - sinF);
-			to.y += 1 / kappa * (-c + cosF);
+			to.x += invKappa * (s - sinF);
+			to.y += invKappa * (-c + cosF);
 		} else {
 			to.x += d * cosF;
 			to.y += d * sinF;

@@ -25,6 +25,7 @@ constexpr int kMaxPrimitives = 128;
 struct PrimTable {
 	int n;
 	double kappa[kMaxPrimitives];
+	double invKappa[kMaxPrimitives]; // 1 / kappa as the host divides it (= the device's own `1 / kappa`, both correctly rounded); unused when |kappa| <= 1e-9
 	int8_t backward[kMaxPrimitives];
 };
 

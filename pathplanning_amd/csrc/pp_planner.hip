@@ -569,6 +569,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				a.sinF = pSin;
 				a.cosF = pCos;
 				a.kappa = A.prims.kappa[p];
+				a.invKappa = A.prims.invKappa[p];
 				a.length = A.rp.arcLength;
 				a.backward = A.prims.backward[p];
 				child = a.interpolate_sc(1.0, cs, cc);
@@ -1158,6 +1159,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		const double cosBeta = std::cos(beta);
 		const double DthetaDdist = cosBeta * tanSteering / wheelbase;
 		A.prims.kappa[2 * d] = DthetaDdist;
+		A.prims.invKappa[2 * d] = A.prims.invKappa[2 * d + 1] = DthetaDdist != 0.0 ? 1 / DthetaDdist : 0.0;
 		A.prims.backward[2 * d] = 0;
 		A.prims.kappa[2 * d + 1] = DthetaDdist;
 		A.prims.backward[2 * d + 1] = 1;

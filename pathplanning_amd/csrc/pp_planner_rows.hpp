@@ -683,6 +683,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				a.sinF = pSin;
 				a.cosF = pCos;
 				a.kappa = A.prims.kappa[p];
+				a.invKappa = A.prims.invKappa[p];
 				a.length = A.rp.arcLength;
 				a.backward = A.prims.backward[p];
 				child = a.interpolate_sc(1.0, cs, cc);
