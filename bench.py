@@ -117,19 +117,28 @@ def main():
         return None
 
     def run_steps(k):
-        """k steps = k batches of B queries; up to n_streams of them in flight."""
-        out, timings, pending = None, [], []
-        for s_i in range(k):
-            pl = lanes[s_i % n_streams][3]
-            if len(pending) == n_streams:
-                done = pending.pop(0)
-                out = finish(done)
-                timings.append(done.last_timings())
-            pl.search_batch_dev(d_starts, d_goals, d_seeds)  # asynchronous: wavefront + search enqueued on the lane's stream
-            pending.append(pl)
-        for done in pending:
-            out = finish(done)
-            timings.append(done.last_timings())
+        """k steps = k batches of B queries; up to n_streams of them in flight.  A lane is refilled as soon as ITS batch is
+        done (non-blocking stream query), whichever lane that is: batches differ in length, and a lane that waits for the
+        host to finish with a slower one leaves its 17 GB of fields idle."""
+        out, timings = None, []
+        busy, free = {}, list(range(n_streams))
+        started = finished = 0
+        while finished < k:
+            while free and started < k:
+                li = free.pop(0)
+                lanes[li][3].search_batch_dev(d_starts, d_goals, d_seeds)  # asynchronous: wavefront + search enqueued on the lane's stream
+                busy[li] = lanes[li][3]
+                started += 1
+            ready = [li for li in busy if lanes[li][0].is_idle()]
+            if not ready:
+                time.sleep(0.0005)
+                continue
+            for li in ready:
+                pl = busy.pop(li)
+                out = finish(pl)
+                timings.append(pl.last_timings())
+                free.append(li)
+                finished += 1
         gather_all()
         return out, timings
 

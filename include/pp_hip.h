@@ -47,6 +47,9 @@ int pp_version(void);
 int pp_ctx_create(int device, void* stream, pp_ctx** out);
 int pp_ctx_destroy(pp_ctx* ctx);
 int pp_ctx_synchronize(pp_ctx* ctx);
+/* Non-blocking: *idle = 1 when everything enqueued on the context's stream has completed (hipStreamQuery), else 0.
+ * For callers that keep several contexts busy and refill whichever finishes first. */
+int pp_ctx_is_idle(pp_ctx* ctx, int32_t* idle);
 /* HIP-event timer on the context's stream: start, stop -> milliseconds. */
 int pp_ctx_timer_start(pp_ctx* ctx);
 int pp_ctx_timer_stop(pp_ctx* ctx, float* ms);

@@ -75,6 +75,7 @@ def load():
     L.pp_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     L.pp_ctx_destroy.argtypes = [vp]
     L.pp_ctx_synchronize.argtypes = [vp]
+    L.pp_ctx_is_idle.argtypes = [vp, C.POINTER(C.c_int32)]
     L.pp_ctx_timer_start.argtypes = [vp]
     L.pp_ctx_timer_stop.argtypes = [vp, c_fp]
     L.pp_map_create.argtypes = [vp, C.POINTER(MapDesc), C.POINTER(vp)]

@@ -175,6 +175,19 @@ int pp_ctx_synchronize(pp_ctx* ctx)
 	return PP_OK;
 }
 
+int pp_ctx_is_idle(pp_ctx* ctx, int32_t* idle)
+{
+	if (!ctx || !idle) {
+		set_error("null ctx");
+		return PP_ERR_INVALID;
+	}
+	const hipError_t e = hipStreamQuery(ctx->stream);
+	if (e != hipSuccess && e != hipErrorNotReady)
+		return pph::hip_fail(e, "hipStreamQuery");
+	*idle = e == hipSuccess ? 1 : 0;
+	return PP_OK;
+}
+
 int pp_ctx_timer_start(pp_ctx* ctx)
 {
 	if (!ctx) {

@@ -49,6 +49,12 @@ class Context:
     def synchronize(self):
         check(self.lib.pp_ctx_synchronize(self.h))
 
+    def is_idle(self):
+        """True when everything enqueued on this context's stream has completed (non-blocking)."""
+        idle = C.c_int32(0)
+        check(self.lib.pp_ctx_is_idle(self.h, C.byref(idle)))
+        return bool(idle.value)
+
     def timer_start(self):
         check(self.lib.pp_ctx_timer_start(self.h))
 
