@@ -1038,16 +1038,9 @@ struct pp_planner {
 	double *dStarts = nullptr, *dGoals = nullptr;
 	uint64_t* dSeeds = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-	// optional CU partition (PP_SEARCH_CUS / PP_WF_CUS): internal streams restricted to a subset of the compute units; the
-	// caller's stream waits for them, so the call keeps its stream-ordered meaning
-	hipStream_t searchStream = nullptr, wfStream = nullptr;
 	// the probable longest queries of a batch run one per wave next to the rows kernel (PP_SEARCH_DIRECT), on their own stream
 	hipStream_t directStream = nullptr;
 	hipEvent_t e3 = nullptr;
-	// PP_TAIL_CUS=n: the continuation of the set-aside (longest) queries runs on a stream restricted to n compute units, so the
-	// long-lived search waves stop scattering over every CU (where each one keeps a second wavefront workgroup from fitting)
-	hipStream_t tailStream = nullptr;
-	hipEvent_t eTail0 = nullptr, eTail1 = nullptr;
 	int directCount = 0;
 	float wavefrontMs = 0, searchMs = 0;
 	int lastBatch = 0;
@@ -1081,20 +1074,10 @@ void free_planner(pp_planner* p)
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
-	if (p->tailStream)
-		(void)hipStreamDestroy(p->tailStream);
-	if (p->eTail0)
-		(void)hipEventDestroy(p->eTail0);
-	if (p->eTail1)
-		(void)hipEventDestroy(p->eTail1);
 	if (p->directStream)
 		(void)hipStreamDestroy(p->directStream);
 	if (p->e3)
 		(void)hipEventDestroy(p->e3);
-	if (p->searchStream)
-		(void)hipStreamDestroy(p->searchStream);
-	if (p->wfStream)
-		(void)hipStreamDestroy(p->wfStream);
 	if (p->e0)
 		(void)hipEventDestroy(p->e0);
 	if (p->e1)
@@ -1320,37 +1303,6 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		e = hipEventCreateWithFlags(&p->e3, hipEventDisableTiming);
 	if (e == hipSuccess && p->directCount > 0)
 		e = hipStreamCreateWithFlags(&p->directStream, hipStreamNonBlocking);
-	{
-		// Compute-unit partition between the two kernels of a step.  Why: a wavefront workgroup needs 77 KB of LDS, two fit a CU
-		// -- unless a search wave (14 KB) is resident there, then only one does.  Search waves are few but spread over every
-		// CU, so they halve the wavefront kernels' residency wherever they land.  PP_SEARCH_CUS=n keeps the search on the first
-		// n CUs of the mask order (which interleaves XCDs and shader engines); PP_WF_CUS=k keeps the wavefront on the LAST k.
-		int dev = 0, nCu = 0;
-		(void)hipGetDevice(&dev);
-		(void)hipDeviceGetAttribute(&nCu, hipDeviceAttributeMultiprocessorCount, dev);
-		auto masked = [&](int first, int count, hipStream_t* out) {
-			std::vector<uint32_t> mask((size_t)(nCu + 31) / 32, 0u);
-			for (int i = first; i < first + count && i < nCu; i++)
-				mask[(size_t)i / 32] |= 1u << (i % 32);
-			return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
-		};
-		const char* sc = getenv("PP_SEARCH_CUS");
-		const char* wc = getenv("PP_WF_CUS");
-		const int nS = sc ? atoi(sc) : 0, nW = wc ? atoi(wc) : 0;
-		if (e == hipSuccess && nS > 0 && nS < nCu)
-			e = masked(0, nS, &p->searchStream);
-		if (e == hipSuccess && nW > 0 && nW < nCu)
-			e = masked(nCu - nW, nW, &p->wfStream);
-		const char* tc = getenv("PP_TAIL_CUS");
-		const int nT = tc && p->rowsKernel ? atoi(tc) : 0;
-		if (e == hipSuccess && nT > 0 && nT < nCu) {
-			e = masked(0, nT, &p->tailStream);
-			if (e == hipSuccess)
-				e = hipEventCreateWithFlags(&p->eTail0, hipEventDisableTiming);
-			if (e == hipSuccess)
-				e = hipEventCreateWithFlags(&p->eTail1, hipEventDisableTiming);
-		}
-	}
 	if (e != hipSuccess) {
 		free_planner(p);
 		return pph::hip_fail(e, "planner allocation");
@@ -1430,19 +1382,11 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
 	const char* const dbgEnv = getenv("PP_DEBUG_SKIP"); // timing experiments only (bench.py --debug-skip): 1 = no wavefront, 2 = no search, 3 = set-aside queries are dropped
 	const int dbgSkip = dbgEnv ? atoi(dbgEnv) : 0;
-	hipStream_t const ws = planner->wfStream ? planner->wfStream : s;
-	if (ws != s)
-		PP_HIP_TRY(hipStreamWaitEvent(ws, planner->e0, 0));
 	if (dbgSkip != 1)
-	PP_HIP_TRY(pph::launch_wavefront(ws, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
+		PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
 		planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true, ordered ? starts_dev : nullptr, ordered ? planner->order : nullptr,
 		planner->wfError + 6, planner->orderKeys));
-	PP_HIP_TRY(hipEventRecord(planner->e1, ws));
-	hipStream_t const callerStream = s;
-	if (planner->searchStream)
-		s = planner->searchStream; // the search kernels below go to the partition's stream
-	if (s != ws)
-		PP_HIP_TRY(hipStreamWaitEvent(s, planner->e1, 0));
+	PP_HIP_TRY(hipEventRecord(planner->e1, s));
 	const int nDirect = ordered && planner->directCount > 0 && dbgSkip != 2 ? (planner->directCount < n_queries / 2 ? planner->directCount : n_queries / 2) : 0;
 	planner->args.directCount = nDirect;
 	if (nDirect > 0) {
@@ -1483,19 +1427,10 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 				planner->bandMeta);
 			PP_HIP_TRY(hipGetLastError());
 		}
-		hipStream_t const ts = planner->tailStream ? planner->tailStream : s;
-		if (ts != s && (secondPass || cap1 > 0)) {
-			PP_HIP_TRY(hipEventRecord(planner->eTail0, s));
-			PP_HIP_TRY(hipStreamWaitEvent(ts, planner->eTail0, 0));
-		}
 		if ((secondPass || cap1 > 0) && dbgSkip != 3) // whatever is still set aside: one wave per query (the block count is read on the device)
-			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.listCap), dim3(64), 0, ts, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
+			hipLaunchKernelGGL(k_hybrid_search<false>, dim3(planner->args.listCap), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof,
 				secondPass ? list2 : list1, secondPass ? ctl + 3 : ctl + 1, planner->mtStates, planner->bands, planner->bandInvW, planner->bandMeta, nullptr, 0);
-		if (ts != s && (secondPass || cap1 > 0)) {
-			PP_HIP_TRY(hipEventRecord(planner->eTail1, ts));
-			PP_HIP_TRY(hipStreamWaitEvent(s, planner->eTail1, 0));
-		}
 	} else if (planner->profile)
 		hipLaunchKernelGGL(k_hybrid_search<true>, dim3(n_queries), dim3(64), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields,
 			planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->results, planner->prof, nullptr, nullptr, nullptr, planner->bands, planner->bandInvW, planner->bandMeta, nullptr, 0);
@@ -1506,8 +1441,6 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	if (nDirect > 0)
 		PP_HIP_TRY(hipStreamWaitEvent(s, planner->e3, 0)); // before e2: the search time covers both kernels
 	PP_HIP_TRY(hipEventRecord(planner->e2, s));
-	if (s != callerStream)
-		PP_HIP_TRY(hipStreamWaitEvent(callerStream, planner->e2, 0));
 	planner->lastBatch = n_queries;
 	return PP_OK;
 }
