@@ -270,3 +270,32 @@ def test_handles_may_be_destroyed_in_any_order():
     res = planner.search_batch(starts, goals, np.array([7, 8], dtype=np.uint64))
     assert res[0].n_expanded > 0 and res[1].n_expanded > 0
     planner.close()
+
+
+def test_context_idle_query_is_non_blocking():
+    """pp_ctx_is_idle: false while a batch enqueued with search_batch_dev is still running (or at the latest true once
+    fetch_results has synchronised), true on an idle stream; the batch's results are unaffected by the polling."""
+    import torch
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    import pathplanning_amd as pa
+    assert ctx.is_idle()
+    n = 40
+    rng = np.random.RandomState(5)
+    starts = valid_random_poses(rng, w, n)
+    goals = valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 9
+    planner = pa.HybridAStarBatch(val, pa.HybridAStarSearchParameters(), max_batch=n, max_nodes=32768)
+    planner.initialize()
+    ref = planner.search_batch(starts, goals, seeds)
+    dev = torch.device("cuda", 0)
+    ds, dg = torch.from_numpy(starts).to(dev), torch.from_numpy(goals).to(dev)
+    dseed = torch.from_numpy(seeds.astype(np.int64)).to(dev)
+    planner.search_batch_dev(ds, dg, dseed)
+    polls = 0
+    while not ctx.is_idle():
+        polls += 1
+        assert polls < 10_000_000
+    res = planner.fetch_results()
+    assert ctx.is_idle()
+    assert [r.n_expanded for r in res] == [r.n_expanded for r in ref]
+    planner.close()
