@@ -48,7 +48,7 @@ def build_pyplanning(force=False, verbose=True):
     host = os.path.join(HERE, "host")
     ext = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
     out = os.path.join(LIB_DIR, "pyplanning" + ext)
-    srcs = [os.path.join(host, "pyplanning.cpp"), os.path.join(host, "planner_hip.hpp"), os.path.join(HERE, "..", "include", "pp_hip.h")]
+    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith((".cpp", ".hpp"))] + [os.path.join(HERE, "..", "include", "pp_hip.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(x) <= os.path.getmtime(out) for x in srcs):
         return out
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],

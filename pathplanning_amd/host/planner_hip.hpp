@@ -13,8 +13,10 @@
 #pragma once
 
 #include <array>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -71,11 +73,31 @@ struct Pose2d { // geometry/2dplane.h:17-45: 3 contiguous doubles, constructors 
 };
 static_assert(sizeof(Pose2d) == 24, "Pose2d must be 3 contiguous doubles (the ABI's pose layout)");
 
-struct GridCellPosition { // utils/grid.h:8-22
+struct GridCellPosition { // utils/grid.h:8-22, utils/grid.cpp:6-66
 	int row = -1, col = -1;
 	GridCellPosition() = default;
 	GridCellPosition(int r, int c) : row(r), col(c) { }
 	bool IsValid() const { return row >= 0 && col >= 0; }
+	bool operator==(const GridCellPosition& o) const { return row == o.row && col == o.col; }
+	bool operator!=(const GridCellPosition& o) const { return !(*this == o); }
+	bool IsAdjacentTo(const GridCellPosition& o) const { return !(*this == o) && std::abs(row - o.row) <= 1 && std::abs(col - o.col) <= 1; }
+	bool IsDiagonalTo(const GridCellPosition& o) const { return row != o.row && col != o.col; }
+	/// in-grid 8-neighbours in the reference's enumeration order (grid.cpp:29-47):
+	/// the column-1 side (same row, row-1, row+1), the column+1 side (same order), then (row-1, col), (row+1, col)
+	std::vector<GridCellPosition> GetNeighbors(int rows, int columns) const
+	{
+		std::vector<GridCellPosition> out;
+		if (!IsValid())
+			return out;
+		out.reserve(8);
+		static const int kStep[8][2] = { { 0, -1 }, { -1, -1 }, { 1, -1 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { -1, 0 }, { 1, 0 } };
+		for (const auto& d : kStep) {
+			const int r = row + d[0], c = col + d[1];
+			if (r >= 0 && r < rows && c >= 0 && c < columns)
+				out.push_back({ r, c });
+		}
+		return out;
+	}
 };
 
 inline void ppCheck(int rc)

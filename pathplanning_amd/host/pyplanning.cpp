@@ -5,12 +5,14 @@
 // HybridAStarStats, PathPlannerSE2Base, HybridAStar; new surface: search_batch, RRT / RRTStar (the reference
 // does not bind RRT).  Map authoring classes (shapes, ObstacleListOccupancyMap, GVD) and paths are not part
 // of the hot path and are not bound.
+#include <pybind11/functional.h>
 #include <pybind11/numpy.h>
 #include <pybind11/operators.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
 #include "planner_hip.hpp"
+#include "a_star.hpp"
 
 namespace py = pybind11;
 using namespace Planner;
@@ -46,6 +48,9 @@ PYBIND11_MODULE(pyplanning, m)
 		.def(py::init<int, int>())
 		.def_readwrite("row", &GridCellPosition::row)
 		.def_readwrite("col", &GridCellPosition::col)
+		.def(py::self == py::self)
+		.def(py::self != py::self)
+		.def("__hash__", [](const GridCellPosition& c) { return std::hash<GridCellPosition>()(c); })
 		.def("__repr__", [](const GridCellPosition& c) { return "<GridCellPosition: row " + std::to_string(c.row) + ", col: " + std::to_string(c.col) + ">"; });
 
 	py::class_<StateSpaceSE2, Ref<StateSpaceSE2>>(m, "StateSpaceSE2")
@@ -55,7 +60,11 @@ PYBIND11_MODULE(pyplanning, m)
 		.def("validate_bounds", &StateSpaceSE2::ValidateBounds)
 		.def_readonly("bounds", &StateSpaceSE2::bounds);
 
-	py::class_<OccupancyMap, Ref<OccupancyMap>>(m, "OccupancyMap")
+	struct OccupancyMapWrapper : OccupancyMap { // pyplanning.cpp:337-341: Python may subclass the map
+		using OccupancyMap::OccupancyMap;
+		bool IsOccupied(const GridCellPosition& a) override { PYBIND11_OVERRIDE(bool, OccupancyMap, IsOccupied, a); }
+	};
+	py::class_<OccupancyMap, Ref<OccupancyMap>, OccupancyMapWrapper>(m, "OccupancyMap")
 		.def(py::init<float>())
 		.def("initialize_size", &OccupancyMap::InitializeSize)
 		.def("rows", &OccupancyMap::Rows)
@@ -156,6 +165,53 @@ PYBIND11_MODULE(pyplanning, m)
 					out.append(py::make_tuple(res[i].status, res[i].cost, res[i].n_expanded, res[i].n_path));
 				return out;
 			});
+
+	// ---- grid A* (pyplanning.cpp:124-197): cost / heuristic are Python callables per edge, as in the reference ----
+	py::class_<NullAction>(m, "NullAction").def(py::init<>());
+	using AStarHeuristicN2 = AStarHeuristic<GridCellPosition>;
+	struct AStarHeuristicN2Wrapper : AStarHeuristicN2 {
+		using AStarHeuristicN2::AStarHeuristicN2;
+		double GetHeuristicValue(const GridCellPosition& state) override { PYBIND11_OVERRIDE_PURE(double, AStarHeuristicN2, GetHeuristicValue, state); }
+		void SetGoal(const GridCellPosition& goal) override { PYBIND11_OVERRIDE_PURE(void, AStarHeuristicN2, SetGoal, goal); }
+	};
+	py::class_<AStarHeuristicN2, Ref<AStarHeuristicN2>, AStarHeuristicN2Wrapper>(m, "AStarHeuristicN2").def(py::init<>());
+	py::class_<AStarHeuristicFcnN2, Ref<AStarHeuristicFcnN2>, AStarHeuristicN2>(m, "AStarHeuristicFcnN2").def(py::init<CellCostFcn>());
+	py::class_<AverageHeuristic<GridCellPosition>, Ref<AverageHeuristic<GridCellPosition>>, AStarHeuristicN2>(m, "AverageHeuristicN2");
+
+	using AStarStatePropagatorN2 = AStarStatePropagator<GridCellPosition>;
+	struct AStarStatePropagatorN2Wrapper : AStarStatePropagatorN2 {
+		using AStarStatePropagatorN2::AStarStatePropagatorN2;
+		using ReturnType = std::vector<std::tuple<GridCellPosition, NullAction, double>>;
+		ReturnType GetNeighborStates(const GridCellPosition& cell) override { PYBIND11_OVERRIDE_PURE(ReturnType, AStarStatePropagatorN2, GetNeighborStates, cell); }
+	};
+	py::class_<AStarStatePropagatorN2, Ref<AStarStatePropagatorN2>, AStarStatePropagatorN2Wrapper>(m, "AStarStatePropagatorN2").def(py::init<>());
+	py::class_<AStarStatePropagatorFcnN2, Ref<AStarStatePropagatorFcnN2>, AStarStatePropagatorN2>(m, "AStarStatePropagatorFcnN2")
+		.def(py::init<const Ref<OccupancyMap>&, const CellCostFcn&>());
+
+	struct PathPlannerN2BaseWrapper : PathPlannerN2Base {
+		using PathPlannerN2Base::PathPlannerN2Base;
+		Status SearchPath() override { PYBIND11_OVERRIDE_PURE(Status, PathPlannerN2Base, SearchPath); }
+		std::vector<GridCellPosition> GetPath() const override { PYBIND11_OVERRIDE_PURE(std::vector<GridCellPosition>, PathPlannerN2Base, GetPath); }
+	};
+	py::class_<PathPlannerN2Base, PathPlannerN2BaseWrapper>(m, "PathPlannerN2Base")
+		.def(py::init<>())
+		.def("search_path", &PathPlannerN2Base::SearchPath)
+		.def("get_path", &PathPlannerN2Base::GetPath)
+		.def("set_init_state", &PathPlannerN2Base::SetInitState)
+		.def("set_goal_state", &PathPlannerN2Base::SetGoalState);
+	py::class_<AStarN2, PathPlannerN2Base>(m, "AStarN2")
+		.def(py::init<>())
+		.def("initialize", &AStarN2::Initialize)
+		.def("get_explored_states", &AStarN2::GetExploredStates)
+		.def("get_expansion_order", &AStarN2::GetExpansionOrder)
+		.def("get_optimal_cost", &AStarN2::GetOptimalCost);
+	py::class_<BidirectionalAStarN2, PathPlannerN2Base>(m, "BidirectionalAStarN2")
+		.def(py::init<>())
+		.def_static("get_average_heuristic_pair", &BidirectionalAStarN2::GetAverageHeuristicPair)
+		.def("initialize", &BidirectionalAStarN2::Initialize)
+		.def("get_explored_states", &BidirectionalAStarN2::GetExploredStates)
+		.def("get_expansion_orders", &BidirectionalAStarN2::GetExpansionOrders)
+		.def("get_optimal_cost", &BidirectionalAStarN2::GetOptimalCost);
 
 	py::class_<RRTParameters>(m, "RRTParameters")
 		.def(py::init<>())
