@@ -633,6 +633,25 @@ void ppo_grid_result_get(void* rv, int* path, int* explored, int* exploredR)
 }
 void ppo_grid_result_destroy(void* rv) { delete (GridResultHandle*)rv; }
 
+// ------------------------------------------------------------- Tree kNN ----
+/// utils/tree.h:73-116 on the oracle's PointTree: points inserted in order (root, then Extend from the previous node),
+/// k nearest of `query` in ascending squared distance; returns how many were found.
+int ppo_tree_knn(int n, const double* points, const double* query, int k, int* outIdx)
+{
+	PointTree tree;
+	for (int i = 0; i < n; i++) {
+		Point2d p { points[2 * i], points[2 * i + 1] };
+		if (i == 0)
+			tree.CreateRoot(p);
+		else
+			tree.Extend(p, i - 1);
+	}
+	std::vector<int> nn = tree.Nearest(Point2d { query[0], query[1] }, (unsigned int)k);
+	for (size_t i = 0; i < nn.size(); i++)
+		outIdx[i] = nn[i];
+	return (int)nn.size();
+}
+
 // ----------------------------------------------------------- RRT / RRT* ----
 /// params = {maxIteration, maxNumberTreeNode, maxConnectionDistance, goalBias}
 void* ppo_rrt(void* wv, const double* lb, const double* ub, const double* params, const double* init, const double* goal, uint64_t seed, int star)

@@ -387,6 +387,15 @@ def rrt(world, lb, ub, init, goal, seed, star=False, max_iteration=100, max_node
                 n_edge_checks=int(info[5]))
 
 
+def tree_knn(points, query, k):
+    """k nearest tree nodes of `query` through the oracle's PointTree (utils/tree.h:73-116 restated)."""
+    points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
+    query = np.ascontiguousarray(query, dtype=np.float64)
+    out = np.empty(max(k, 1), dtype=np.int32)
+    n = lib().ppo_tree_knn(C.c_int(len(points)), dptr(points), dptr(query), C.c_int(k), iptr(out))
+    return out[:n]
+
+
 def frontier_replay(ops, costs, mode=0):
     ops = np.ascontiguousarray(ops, dtype=np.int32)
     costs = np.ascontiguousarray(costs, dtype=np.float64)

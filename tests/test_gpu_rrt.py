@@ -94,3 +94,47 @@ def test_rrt_batch_equals_single_runs_and_oracle():
             want = O.rrt(w, lb, ub, inits[i], goals[i], int(seeds[i]), star=star, max_iteration=5000, max_nodes=5000, max_connection=0.512, goal_bias=0.05)
             same_tree(got[i], want)
         assert len(got[3]["nodes"]) > 2048
+
+
+def test_config3_full_size_rrt_star():
+    """BASELINE config 3 at full size: RRT* on a 1024 x 1024 map, maxIteration = maxNumberTreeNode = 1e5,
+    maxConnectionDistance 2.048 m, goalBias 0.05, k = floor(ln N); the goal sits inside an obstacle's clearance so no
+    iteration is skipped.  The whole tree (parents, costs, counters) must equal the oracle's; on top, size-independent
+    invariants: parents precede children, cost = parent cost + edge length."""
+    import time
+    import pathplanning_amd as pa
+    from pathplanning_amd import synthetic
+    ctx = pa.Context(0)
+    m = synthetic.make_map(1024, 24, seed=1)
+    ms, val = synthetic.upload(ctx, m)
+    ow = O.World(float(m["upper"][0]), float(m["upper"][1]), m["resolution"])
+    ow.set_occ(m["occ"])
+    ow.set_d2(m["d2"])
+    ow.set_pathcost(m["path_cost"])
+    lb, ub = np.array(m["lower"][:2]), np.array(m["upper"][:2])
+    rng = np.random.RandomState(0)
+    while True:
+        g = rng.uniform(lb * 0.6, ub * 0.6)
+        if not val.is_state_valid(np.array([[g[0], g[1], 0.0]]))[0]:
+            break
+    N = 100000
+    r = pa.RRTStar(ctx, lb, ub, validator=val, max_iteration=N, max_number_tree_node=N, max_connection_distance=2.048, goal_bias=0.05)
+    r.set_init_state([-46.0, -46.0])
+    r.set_goal_state(g)
+    r.set_seed(7)
+    t = time.time()
+    r.search_path()
+    gpu_s = time.time() - t
+    got = r.result
+    assert got["iterations"] == N + 1  # `count > maxIteration` (rrt_star.h:62, Appendix A Q15)
+    nodes, parents, costs = got["nodes"], got["parents"], got["costs"]
+    assert len(nodes) > 50000
+    idx = np.arange(1, len(nodes))
+    assert (parents[idx] < idx).all() and (parents[idx] >= 0).all()
+    edge = np.hypot(*(nodes[idx] - nodes[parents[idx]]).T)
+    assert np.abs(costs[idx] - (costs[parents[idx]] + edge)).max() < 1e-9
+    t = time.time()
+    want = O.rrt(ow, lb, ub, [-46.0, -46.0], g, 7, star=True, max_iteration=N, max_nodes=N, max_connection=2.048, goal_bias=0.05)
+    cpu_s = time.time() - t
+    same_tree(got, want)
+    print("config 3: %d iterations, %d nodes; GPU %.2f s, CPU oracle (brute-force kNN, 1 core) %.1f s" % (got["iterations"], len(nodes), gpu_s, cpu_s))
