@@ -36,8 +36,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8, help="untimed steps; the default touches every batch lane once")
-    ap.add_argument("--batch", type=int, default=4096, help="queries per GPU per step")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed steps; at least one per batch lane is always run (a lane's first batch is cold), whatever is asked")
+    ap.add_argument("--batch", type=int, default=4096, help="queries per GPU per step (weak scaling) / per step in total (strong scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank runs --batch queries per step (the default the driver's 1/2/4/8 curve uses); strong: BASELINE configs[3] "
+                         "literally -- --batch queries per step in total, block-cyclic over the ranks (512 per GPU at 8 GPUs)")
     ap.add_argument("--cells", type=int, default=1024)
     ap.add_argument("--obstacles", type=int, default=24)
     ap.add_argument("--max-nodes", type=int, default=81920, help=">= number of (x, y, aliased heading) cells: no query can run out of nodes")
@@ -63,6 +66,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     n_gpus = max(world, 1)
+    if args.gpus != n_gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                         "--master-port P bench.py --gpus N ...` (one rank per GPU)" % (args.gpus, n_gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -71,7 +77,8 @@ def main():
 
     m = synthetic.make_map(args.cells, args.obstacles, seed=1)
     params = pa.HybridAStarSearchParameters()
-    B = args.batch
+    from pathplanning_amd import sharding
+    B = args.batch if args.scaling == "weak" else len(sharding.shard_indices(args.batch, rank, max(world, 1)))
     # Batches are independent, and one batch alone cannot fill the GPU (its search kernel is bound by the longest
     # query): keep `streams` batches in flight, each on its own HIP stream with its own planner workspace.
     n_streams = max(1, args.streams)
@@ -87,10 +94,15 @@ def main():
 
     # queries: uniform over valid poses; every rank its own slice of the seed space
     reach = synthetic.reachable_mask(val, m)  # drop the pockets enclosed by outline obstacles
-    starts = synthetic.sample_valid_poses(val, m, B, seed=1000 + rank, reachable=reach)
-    goals = synthetic.sample_valid_poses(val, m, B, seed=2000 + rank, reachable=reach)
     from pathplanning_amd import sharding
-    my_ids = sharding.shard_indices(B * max(world, 1), rank, max(world, 1))  # global query ids owned by this rank (block-cyclic)
+    total_queries = B * max(world, 1) if args.scaling == "weak" else args.batch
+    my_ids = sharding.shard_indices(total_queries, rank, max(world, 1))  # global query ids owned by this rank (block-cyclic)
+    if args.scaling == "weak":  # every rank its own slice of the seed space
+        starts = synthetic.sample_valid_poses(val, m, B, seed=1000 + rank, reachable=reach)
+        goals = synthetic.sample_valid_poses(val, m, B, seed=2000 + rank, reachable=reach)
+    else:  # one global query set, the same on every rank; each rank plans the queries it owns
+        starts = np.ascontiguousarray(synthetic.sample_valid_poses(val, m, args.batch, seed=1000, reachable=reach)[my_ids])
+        goals = np.ascontiguousarray(synthetic.sample_valid_poses(val, m, args.batch, seed=2000, reachable=reach)[my_ids])
     seeds = my_ids.astype(np.uint64)
     d_starts = torch.from_numpy(starts).to(dev)
     d_goals = torch.from_numpy(goals).to(dev)
@@ -111,7 +123,7 @@ def main():
             k = len(step_records)
             rec = np.concatenate(step_records)  # [k * B, fields], step-major
             rec = rec.reshape(k, B, -1).transpose(1, 0, 2).reshape(B, -1)  # one row per local query, k records wide
-            out = sharding.gather_records(rec, B * world, rank, world, device=dev)
+            out = sharding.gather_records(rec, total_queries, rank, world, device=dev)
             step_records.clear()
             return out
         return None
@@ -147,10 +159,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if args.warmup:
-        run_steps(args.warmup)
+    # every lane's first batch is cold (first touch of its 17 GB of fields, first dispatch of its kernels): the warm-up runs
+    # at least one batch through each lane, so no cold batch falls into the timed region whatever --warmup says
+    # (round 1's driver run, --warmup 5 with 8 lanes, timed three cold batches)
+    warm = max(args.warmup, n_streams)
+    run_steps(warm)
     sync_all()
     if args.debug_skip:
+        if "PP_HIP_LIB" not in os.environ:
+            raise SystemExit("--debug-skip needs a diagnostic build of the library: python tools/build_variant.py skip -DPP_ENABLE_DEBUG_SKIP=1, "
+                             "then PP_HIP_LIB=pathplanning_amd/lib/variants/skip.so (the shipped library has no work-skipping path)")
         os.environ["PP_DEBUG_SKIP"] = str(args.debug_skip)
     t0 = time.perf_counter()
     res, timings = run_steps(args.steps)
@@ -162,7 +180,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    plans_per_s = B * n_gpus * args.steps / elapsed
+    total_per_step = B * n_gpus if args.scaling == "weak" else args.batch
+    plans_per_s = total_per_step * args.steps / elapsed
     n_success = sum(1 for r in res if r.status == 0)
     n_expanded = sum(r.n_expanded for r in res)
     n_children = n_expanded * planner.num_primitives
@@ -178,6 +197,7 @@ def main():
     poses[:, 1].uniform_(-half, half, generator=g)
     poses[:, 2].uniform_(-3.141592653589793, 3.141592653589793, generator=g)
     out = torch.empty(n_chk, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)  # the poses are filled on torch's stream, the checks run on the library's own
     lib = ctx.lib
     from pathplanning_amd._lib import check
     import ctypes as C
@@ -235,7 +255,15 @@ def main():
             cores = min(os.cpu_count() or 1, 16)
             secs, st, cost, nexp = O.hybrid_batch(ow, table, starts[:ns], goals[:ns], seeds[:ns], threads=cores)
             agree = sum(1 for i in range(ns) if st[i] == res[i].status and (st[i] != 0 or abs(cost[i] - res[i].cost) < 1e-5) and nexp[i] == res[i].n_expanded)
-            cpu = dict(value=ns / secs, unit="plans/s", cores=cores, kind="port",
+            model = ""
+            try:
+                for ln in open("/proc/cpuinfo"):
+                    if ln.startswith("model name"):
+                        model = ln.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
+            cpu = dict(value=ns / secs, unit="plans/s", cores=cores, cpu_model=model, host_cpus=os.cpu_count(), kind="port",
                        sample="first %d of the %d benchmark queries, oracle HybridAStar::Search (heap wavefront + graph search), %d threads" % (ns, B, cores),
                        agree_with_gpu="%d/%d" % (agree, ns))
         except Exception as e:  # the bench line must still be printed
@@ -249,10 +277,11 @@ def main():
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_run": warm,
             **({"INVALID_debug_skip": args.debug_skip} if args.debug_skip else {}),
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

@@ -17,7 +17,9 @@ c_u64p = C.POINTER(C.c_uint64)
 
 
 class PPError(RuntimeError):
-    pass
+    """A libpphip call returned a negative code (include/pp_hip.h: PP_ERR_INVALID -1, PP_ERR_HIP -2, PP_ERR_NO_DEVICE -3,
+    PP_ERR_CAPACITY -4); `code` holds it, the text is pp_last_error()."""
+    code = 0
 
 
 class MapDesc(C.Structure):
@@ -131,7 +133,9 @@ def load():
 
 def check(rc):
     if rc != 0:
-        raise PPError("libpphip error %d: %s" % (rc, load().pp_last_error().decode()))
+        e = PPError("libpphip error %d: %s" % (rc, load().pp_last_error().decode()))
+        e.code = rc
+        raise e
 
 
 def ptr(a):

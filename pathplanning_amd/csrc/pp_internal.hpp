@@ -69,6 +69,9 @@ struct WavefrontWorkspace;
 int64_t wavefront_workspace_bytes(int rows, int cols);
 /// workgroups of the wavefront kernel that are resident at once on the current device (occupancy API x CUs)
 int wavefront_resident_blocks();
+/// one empty dispatch of the wavefront kernel (no goal to take): makes the stream's queue allocate the kernel's scratch now;
+/// ctlDev: >= 8 zeroed bytes of device memory (error flag, goal counter)
+hipError_t warm_up_wavefront(hipStream_t s, const ppd::MapView& m, int32_t* ctlDev);
 /// Runs nGoals wavefronts; goalCells[g] = row*cols+col or -1 (goal outside the map -> field stays +inf).
 /// orderStartsDev / orderOutDev / doneCounterDev / orderKeysDev[nGoals] (optional, nGoals <= 4096): the last workgroup writes the goal indices ordered by
 /// decreasing field value at the start pose (x, y, theta triples) -- the planner's hand-out order; *doneCounterDev must be 0.

@@ -21,6 +21,9 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <string>
+#include <utility>
+#include <vector>
 
 using namespace ppd;
 
@@ -1051,6 +1054,46 @@ namespace {
 
 using pph::set_error;
 
+// Scratch the planner's kernels need per lane (largest private segment among them; tests/test_kernel_resources.py keeps
+// the figure honest against the built code object) and the number of hardware queues whose first dispatch may still have to
+// allocate it after this planner took its memory (bench.py runs with GPU_MAX_HW_QUEUES=16).
+constexpr size_t kMaxPrivateBytes = 512;
+constexpr size_t kReserveQueues = 16;
+
+/// Empty dispatches of the three kernels a batch launches, on the planner's stream, then a synchronisation: the queue
+/// allocates their scratch here, where a failure is an error code, not at the first batch, where it is an abort.
+int warm_up_kernels(pp_planner* p, pp_map* map)
+{
+	hipStream_t s = map->ctx->stream;
+	int32_t* ctl = nullptr;
+	PP_HIP_TRY(hipMalloc((void**)&ctl, 64));
+	hipError_t e = hipMemsetAsync(ctl, 0, 64, s);
+	if (e == hipSuccess)
+		e = pph::warm_up_wavefront(s, map->view(), ctl);
+	if (e == hipSuccess) {
+		SearchArgs none = p->args;
+		none.rowsWaves = 0; // every wave of the rows kernel leaves at once
+		none.listCap = 0;
+		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(1), dim3(64 * PP_ROWS_WAVES_PER_WG), 0, s, none, 0, (const double*)nullptr, (const double*)nullptr, (const uint64_t*)nullptr,
+			(const float*)nullptr, (Node*)nullptr, (HeapEntry*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (RsLogEntry*)nullptr, (PathRec*)nullptr, (unsigned long long*)nullptr,
+			(DevResult*)nullptr, (int*)nullptr, (SuspendRec*)nullptr, (const int32_t*)nullptr, 0, (const SuspendRec*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr, 0,
+			(HeapEntry*)nullptr, 0.0, (uint8_t*)nullptr);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_hybrid_search<false>, dim3(1), dim3(64), 0, s, p->args, 0, (const double*)nullptr, (const double*)nullptr, (const uint64_t*)nullptr, (const float*)nullptr,
+			(Node*)nullptr, (HeapEntry*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (RsLogEntry*)nullptr, (PathRec*)nullptr, (DevResult*)nullptr, (unsigned long long*)nullptr,
+			(const SuspendRec*)nullptr, (const int*)nullptr, (const unsigned long long*)nullptr, (HeapEntry*)nullptr, 0.0, (uint8_t*)nullptr, (const int32_t*)nullptr, 0);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(s);
+	(void)hipFree(ctl);
+	if (e != hipSuccess)
+		return pph::hip_fail(e, "planner kernel warm-up (scratch allocation)");
+	return PP_OK;
+}
+
 void free_planner(pp_planner* p)
 {
 	if (!p)
@@ -1239,35 +1282,47 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		// eight batches in flight (measured: 32768 -> 10.2 k plans/s, 8192 -> 8.0 k, never -> 9.8 k).  Optionally a second
 		// pass of the rows kernel continues the set-aside queries up to `suspendAfter2` first (PP_SEARCH_SUSPEND_AFTER2;
 		// measured no better: 8192 / 32768 -> 7.6 k, 12288 / 32768 -> 10.1 k).  PP_SEARCH_SUSPEND_AFTER=0: no hand-over.
-		const char* cap = getenv("PP_SEARCH_SUSPEND_AFTER");
-		A.suspendAfter = p->rowsKernel ? (cap ? atoi(cap) : 32768) : 0;
-		const char* cap2 = getenv("PP_SEARCH_SUSPEND_AFTER2");
-		A.suspendAfter2 = cap2 ? atoi(cap2) : 0;
-		const char* ex = getenv("PP_SEARCH_EXTRA_SLOTS");
-		A.extraSlots = A.suspendAfter > 0 ? (ex ? atoi(ex) : (max_batch + 15) / 16) : 0; // queries that may be set aside (the rest stays)
+		// tuning knobs from the environment are clamped to their meaningful ranges: none of them may change results or
+		// make an allocation size negative
+		auto env_int = [](const char* name, int dflt, int lo, int hi) {
+			const char* v = getenv(name);
+			if (!v || !*v)
+				return dflt;
+			const long x = strtol(v, nullptr, 10);
+			return (int)(x < lo ? lo : (x > hi ? hi : x));
+		};
+		A.suspendAfter = p->rowsKernel ? env_int("PP_SEARCH_SUSPEND_AFTER", 32768, 0, 1 << 30) : 0;
+		A.suspendAfter2 = env_int("PP_SEARCH_SUSPEND_AFTER2", 0, 0, 1 << 30);
+		A.extraSlots = A.suspendAfter > 0 ? env_int("PP_SEARCH_EXTRA_SLOTS", (max_batch + 15) / 16, 0, max_batch) : 0; // queries that may be set aside (the rest stays)
 		A.searchRows = p->searchRows;
 		A.listCap = A.extraSlots + p->searchRows;
 		// A batch lasts as long as its longest query, and a query is a chain of dependent expansions: it runs faster alone in
 		// a wave (k_hybrid_search: ~11 us per expansion) than as one of four (rows kernel: 15-20 us).  The wavefront kernel
 		// already ranks the queries by probable length for the hand-out order; the first PP_SEARCH_DIRECT of that order get
 		// a wave of their own, in slots behind the spare ones.
-		const char* dc = getenv("PP_SEARCH_DIRECT");
-		p->directCount = p->rowsKernel ? (dc ? atoi(dc) : 0) : 0;
-		if (p->directCount < 0 || p->directCount > max_batch / 2)
-			p->directCount = 0;
+		p->directCount = p->rowsKernel ? env_int("PP_SEARCH_DIRECT", 0, 0, max_batch / 2) : 0;
 		A.directCount = 0; // set per call (only when the order is available)
 		// compaction (pp_planner_rows.hpp): waves whose queue is empty and that have at most this many busy rows re-queue
 		// their queries for a second pass that packs them four per wave.  Off by default: it issues fewer instructions
 		// (a wave costs the same with one busy row as with four) but the passes of one batch run one after the other, and
 		// with eight batches in flight the longer per-batch latency costs more than the saved issue slots
 		// (measured: 8.1 k plans/s with PP_SEARCH_COMPACT=2 against 10.9 k without).
-		const char* cpt = getenv("PP_SEARCH_COMPACT");
-		p->compactBelow = p->rowsKernel && cpt ? atoi(cpt) : 0;
+		p->compactBelow = p->rowsKernel ? env_int("PP_SEARCH_COMPACT", 0, 0, kRowsPerWave) : 0;
 	}
 	hipError_t e = hipSuccess;
+	// Headroom.  The kernels this planner launches need scratch (private segment: k_hybrid_search_rows 408 B, k_wavefront
+	// 132 B, k_hybrid_search 112 B per lane, tools/kernel_resources.py), which the runtime allocates per hardware queue at a
+	// kernel's FIRST dispatch: private bytes x 64 lanes x every wave slot of the device.  A planner that takes the last byte
+	// of HBM makes that allocation fail and the runtime aborts the process (round 1: HSA_STATUS_ERROR_OUT_OF_RESOURCES in
+	// k_wavefront after a 2048-row planner).  So: (i) the kernels are dispatched once with empty grids BEFORE the large
+	// allocations, which makes this stream's queue allocate its scratch now, and (ii) the planner refuses to take memory
+	// beyond free - reserve, where the reserve covers the same scratch for the other hardware queues a process may use.
+	size_t planned = 0;
+	std::vector<std::pair<void**, size_t>> wanted;
 	auto alloc = [&](void** ptr, size_t bytes) {
-		if (e == hipSuccess)
-			e = hipMalloc(ptr, bytes ? bytes : 1);
+		bytes = bytes ? bytes : 1;
+		wanted.push_back({ ptr, bytes });
+		planned += (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); // the allocator works in 2 MiB granules
 	};
 	alloc((void**)&p->table, tableBytes);
 	alloc((void**)&p->costFields, B * (size_t)A.fieldElems * sizeof(float));
@@ -1293,6 +1348,30 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->dStarts, B * 24);
 	alloc((void**)&p->dGoals, B * 24);
 	alloc((void**)&p->dSeeds, B * 8);
+	{
+		if (int rc = warm_up_kernels(p, map)) {
+			free_planner(p);
+			return rc;
+		}
+		size_t freeB = 0, totalB = 0;
+		e = hipMemGetInfo(&freeB, &totalB);
+		int dev = 0;
+		hipDeviceProp_t prop;
+		size_t reserve = (size_t)1 << 30;
+		if (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+			const size_t waveSlots = (size_t)prop.multiProcessorCount * 32; // 8 waves on each of a CU's 4 SIMDs
+			reserve += (size_t)kMaxPrivateBytes * 64 * waveSlots * kReserveQueues;
+		}
+		if (e == hipSuccess && planned + reserve > freeB) {
+			free_planner(p);
+			set_error("planner needs " + std::to_string(planned >> 20) + " MiB, the device has " + std::to_string(freeB >> 20) + " MiB free and " +
+				std::to_string(reserve >> 20) + " MiB stay reserved for kernel scratch");
+			return PP_ERR_CAPACITY;
+		}
+		for (auto& w : wanted)
+			if (e == hipSuccess)
+				e = hipMalloc(w.first, w.second);
+	}
 	if (e == hipSuccess)
 		e = hipEventCreate(&p->e0);
 	if (e == hipSuccess)
@@ -1380,8 +1459,13 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	static const bool lpt = !(getenv("PP_SEARCH_ORDER") && getenv("PP_SEARCH_ORDER")[0] == '0');
 	const bool ordered = planner->rowsKernel && lpt && n_queries <= 4096 && n_queries > planner->searchRows;
 	// ObstaclesHeuristic::Update for every query's goal (hybrid_a_star.cpp:249)
-	const char* const dbgEnv = getenv("PP_DEBUG_SKIP"); // timing experiments only (bench.py --debug-skip): 1 = no wavefront, 2 = no search, 3 = set-aside queries are dropped
+#ifdef PP_ENABLE_DEBUG_SKIP // diagnostic builds only (tools/build_variant.py skip -DPP_ENABLE_DEBUG_SKIP=1; bench.py --debug-skip): the shipped
+	// library always runs both kernels.  1 = no wavefront launch, 2 = no search launch, 3 = set-aside queries are dropped
+	const char* const dbgEnv = getenv("PP_DEBUG_SKIP");
 	const int dbgSkip = dbgEnv ? atoi(dbgEnv) : 0;
+#else
+	constexpr int dbgSkip = 0;
+#endif
 	if (dbgSkip != 1)
 		PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
 		planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true, ordered ? starts_dev : nullptr, ordered ? planner->order : nullptr,

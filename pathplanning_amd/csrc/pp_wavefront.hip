@@ -205,18 +205,23 @@ __device__ __forceinline__ NbhdRaw nbhd_issue(const uint8_t* __restrict__ state,
 	}
 	return r;
 }
+__device__ __forceinline__ Row3 nbhd_row(unsigned long long w, uint32_t side, int x)
+{
+	// no arrays of pointers / values here: anything indexable ends up in scratch memory (measured: 28 scratch stores and 16
+	// loads per window cell in the round loop, ~280 GB of write-backs per 4096-goal launch)
+	const uint32_t lo = (uint32_t)(w >> ((x ? x - 1 : 0) * 8)) & 0xFFu;
+	const uint32_t hi = (uint32_t)(w >> ((x < 7 ? x + 1 : 7) * 8)) & 0xFFu;
+	Row3 r;
+	r.a = x == 0 ? side : lo;
+	r.b = (uint32_t)(w >> (x * 8)) & 0xFFu;
+	r.c = x == 7 ? side : hi;
+	return r;
+}
 __device__ __forceinline__ void nbhd_finish(const NbhdRaw& r, Row3& up, Row3& mid, Row3& dn)
 {
-	const int x = r.x;
-	Row3* out[3] = { &up, &mid, &dn };
-#pragma unroll
-	for (int k = 0; k < 3; k++) {
-		const uint32_t lo = (uint32_t)(r.w[k] >> ((x ? x - 1 : 0) * 8)) & 0xFFu;
-		const uint32_t hi = (uint32_t)(r.w[k] >> ((x < 7 ? x + 1 : 7) * 8)) & 0xFFu;
-		out[k]->a = x == 0 ? r.side[k] : lo;
-		out[k]->b = (uint32_t)(r.w[k] >> (x * 8)) & 0xFFu;
-		out[k]->c = x == 7 ? r.side[k] : hi;
-	}
+	up = nbhd_row(r.w[0], r.side[0], r.x);
+	mid = nbhd_row(r.w[1], r.side[1], r.x);
+	dn = nbhd_row(r.w[2], r.side[2], r.x);
 }
 __device__ __forceinline__ void load_state_nbhd(const uint8_t* __restrict__ state, int tpr, int pr, int pcc, Row3& up, Row3& mid, Row3& dn)
 {
@@ -240,24 +245,14 @@ constexpr uint32_t ST_FREE = 0u, ST_OCC = 1u, ST_SEEN = 2u; // state grid values
 /// neighbour j is offered iff it is free and undiscovered and the corner rule allows the move.
 __device__ __forceinline__ uint32_t candidate_mask(const Row3& up, const Row3& mid, const Row3& dn)
 {
-	const uint32_t nb[8] = { mid.a, up.a, dn.a, mid.c, up.c, dn.c, up.b, dn.b }; // order of kDr/kDc
 	const bool oL = mid.a == ST_OCC, oR = mid.c == ST_OCC, oU = up.b == ST_OCC, oD = dn.b == ST_OCC;
-	uint32_t mk = 0;
-#pragma unroll
-	for (int j = 0; j < 8; j++) {
-		bool ok = nb[j] == ST_FREE; // not occupied, not yet in the open list nor explored
-		// diagonal: blocked only if BOTH (n.row, cell.col) and (cell.row, n.col) are occupied (heuristics.cpp:130-132)
-		if (j == 1)
-			ok = ok && !(oU && oL);
-		if (j == 2)
-			ok = ok && !(oD && oL);
-		if (j == 4)
-			ok = ok && !(oU && oR);
-		if (j == 5)
-			ok = ok && !(oD && oR);
-		if (ok)
-			mk |= 1u << j;
-	}
+	// bit j = neighbour j in the order of kDr/kDc: free and undiscovered (not occupied, not yet in the open list nor explored)
+	uint32_t mk = (mid.a == ST_FREE ? 1u : 0u) | (mid.c == ST_FREE ? 8u : 0u) | (up.b == ST_FREE ? 64u : 0u) | (dn.b == ST_FREE ? 128u : 0u);
+	// diagonal: blocked only if BOTH (n.row, cell.col) and (cell.row, n.col) are occupied (heuristics.cpp:130-132)
+	mk |= (up.a == ST_FREE && !(oU && oL)) ? 2u : 0u;
+	mk |= (dn.a == ST_FREE && !(oD && oL)) ? 4u : 0u;
+	mk |= (up.c == ST_FREE && !(oU && oR)) ? 16u : 0u;
+	mk |= (dn.c == ST_FREE && !(oD && oR)) ? 32u : 0u;
 	return mk;
 }
 
@@ -536,6 +531,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 	const uint32_t cellMask = (1u << (2 * cb)) - 1u;
 	WfSlot S = slot_view(workspace, bytesPerSlot, blockIdx.x, stBytes, pcells, fcap, gcap);
 	uint8_t* const state = S.state;
+	// the two halves of the HBM list as plain pointers: `S.fent[cur]` with a run-time index keeps the whole struct in scratch
+	// memory (one scratch load per use in the round loop)
+	uint64_t* const fent0 = S.fent[0];
+	uint64_t* const fent1 = S.fent[1];
 	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
 	const int nbOff[8] = { -1, -65536 - 1, 65536 - 1, 1, -65536 + 1, 65536 + 1, -65536, 65536 }; // (row << 16 | col) offsets of kDr/kDc
 	// index of map cell (r, c) in this goal's output field
@@ -612,7 +611,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			if (inLds)
 				lent[0] = (uint64_t)sp; // cost 0
 			else
-				S.fent[0][0] = (uint64_t)sp;
+				fent0[0] = (uint64_t)sp;
 		}
 		__syncthreads();
 
@@ -623,7 +622,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		bool overflow = false;
 
 		while (n > 0) {
-			const int nxt = cur ^ 1;
+			uint64_t* const fentCur = cur ? fent1 : fent0;
+			uint64_t* const fentNxt = cur ? fent0 : fent1;
 			const int par = (int)(round & 1u);
 			const float L = __uint_as_float(lBits);
 			const uint32_t hiBits = __float_as_uint(L + 1.0f);
@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			bool fast = true;
 			uint32_t w = 0, b = 0;
 			uint32_t restMin = 0xFFFFFFFFu;
-			if (inLds) {
+			if (__builtin_expect(inLds, 1)) {
 				uint64_t e[8];
 				unsigned long long bw[8], br[8];
 #pragma unroll
@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 #pragma unroll
 						for (int u = 0; u < 8; u++) {
 							const uint32_t i = i0 + (uint32_t)(u * WF_T + tid);
-							e[u] = i < n ? S.fent[cur][i] : ~0ull;
+							e[u] = i < n ? fentCur[i] : ~0ull;
 							const bool inW = i < n && (uint32_t)(e[u] >> 32) < hiBits;
 							bw[u] = __ballot(inW);
 							br[u] = __ballot(i < n && !inW);
@@ -723,7 +723,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 								}
 							} else if (i < n) {
 								const uint32_t rslot = bRun + (off & 0xFFFFu) + (uint32_t)__popcll(br[u] & ltMask);
-								S.fent[nxt][rslot] = e[u]; // rslot < n <= fcap
+								fentNxt[rslot] = e[u]; // rslot < n <= fcap
 								restMin = min(restMin, c);
 							}
 						}
@@ -752,8 +752,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				break;
 			}
 			const bool prefetched = fast && w > 1 && w <= 4u * WF_T; // masks come out of the sort
-			if (fast) {
-				if (prefetched)
+			if (__builtin_expect(fast, 1)) {
+				if (__builtin_expect(prefetched, 1))
 					rank_sort_masks(skey, hist, s_wsum, smask, w, hiBits - lBits, shiftD, state, tpr, cb, cellMask);
 				else if (w > 1)
 					rank_sort(skey, hist, s_wsum, w, hiBits - lBits, shiftD);
@@ -780,16 +780,16 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				if (pushLds)
 					lent[slot] = ((uint64_t)pb << 32) | ncell;
 				else if (slot < S.fcap)
-					S.fent[nxt][slot] = ((uint64_t)pb << 32) | ncell;
+					fentNxt[slot] = ((uint64_t)pb << 32) | ncell;
 			};
 			// the list leaves LDS before the pushes when they might not fit: survivors are copied to HBM once
 			auto spill_list = [&]() {
 				for (uint32_t i = tid; i < b; i += WF_T)
-					S.fent[nxt][i] = lent[i];
+					fentNxt[i] = lent[i];
 			};
 			uint32_t myCell[4] = { 0, 0, 0, 0 }, myCost[4] = { 0, 0, 0, 0 }, myMask[4] = { 0, 0, 0, 0 };
 			bool hashed = false;
-			if (fast && w <= 4u * WF_T) {
+			if (__builtin_expect(fast && w <= 4u * WF_T, 1)) {
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					const uint32_t i = tid + q * WF_T;
@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				}
 				unsigned long long ts_ = 0;
 				uint32_t cnt = 0;
-				if (prefetched) {
+				if (__builtin_expect(prefetched, 1)) {
 					if (kProfile) {
 						ts_ = clock64();
 						ph[WP_O_WAIT] += ts_ - tl;
@@ -820,18 +820,15 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						ts_ = clock64();
 						ph[WP_O_WAIT] += ts_ - tl;
 					}
-					Row3 up[4], mid[4], dn[4];
-#pragma unroll
-					for (int q = 0; q < 4; q++) {
-						const uint32_t i = tid + q * WF_T;
-						if (i < w)
-							load_state_nbhd(state, tpr, (int)(myCell[q] >> 16), (int)(myCell[q] & 0xFFFFu), up[q], mid[q], dn[q]);
-					}
+					// (rare: single-cell windows and windows beyond 4 x 512 cells never come here with more than one q busy, so
+					// the loads are not batched -- holding 4 x 9 state words live would cost the round loop its registers)
 #pragma unroll
 					for (int q = 0; q < 4; q++) {
 						const uint32_t i = tid + q * WF_T;
 						if (i < w) {
-							myMask[q] = candidate_mask(up[q], mid[q], dn[q]);
+							Row3 up, mid, dn;
+							load_state_nbhd(state, tpr, (int)(myCell[q] >> 16), (int)(myCell[q] & 0xFFFFu), up, mid, dn);
+							myMask[q] = candidate_mask(up, mid, dn);
 							cnt += __popc(myMask[q]);
 						}
 					}
@@ -853,7 +850,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			} else {
 				__syncthreads();
 			}
-			if (hashed) {
+			if (__builtin_expect(hashed, 1)) {
 				// ================= fast path: claims in an LDS hash table (the sort buffer is reused) =================
 				for (int i = tid; i < WF_HCAP / 4; i += WF_T) {
 					reinterpret_cast<uint4*>(hcell)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -1086,10 +1083,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				break;
 			}
 			if (!nextLds) {
-				cur = nxt;
+				cur ^= 1;
 				if (packable && nn <= (uint32_t)WF_LIST / 2) { // small again: bring it back into LDS
 					for (uint32_t i = tid; i < nn; i += WF_T)
-						lent[i] = S.fent[cur][i];
+						lent[i] = fentNxt[i]; // (the list just written)
 					lds_barrier();
 					nextLds = true;
 				}
@@ -1192,6 +1189,14 @@ int wavefront_resident_blocks()
 	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront<false>, WF_T, 0) != hipSuccess || perCu < 1)
 		perCu = 1;
 	return perCu * prop.multiProcessorCount;
+}
+
+hipError_t warm_up_wavefront(hipStream_t s, const MapView& m, int32_t* ctlDev)
+{
+	// nGoals = 0: the workgroup reads the goal counter, finds nothing to do and leaves; no other pointer is dereferenced
+	hipLaunchKernelGGL(k_wavefront<false>, dim3(1), dim3(WF_T), 0, s, m, 0, nullptr, nullptr, nullptr, (int64_t)0, 0u, 0u, ctlDev, nullptr, (int*)(ctlDev + 1), 0, nullptr, nullptr,
+		nullptr, nullptr, nullptr);
+	return hipGetLastError();
 }
 
 hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,

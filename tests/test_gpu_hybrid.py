@@ -364,3 +364,38 @@ def test_device_table_versus_oracle_table_divergence():
     json.dump(line, open(os.path.join(out, "own_table_parity.json"), "w"))
     assert bad_host == []
     assert len(bad_dev) <= n // 50, line  # last-bit table differences may reorder a tie now and then; they must stay rare
+
+
+def test_planners_until_capacity_error_not_an_abort():
+    """Round 1's abort (gpurun_out/b_b2048.log): a planner took the last byte of HBM and the runtime could not allocate the
+    scratch k_wavefront needs at its first dispatch -> HSA_STATUS_ERROR_OUT_OF_RESOURCES, core dump.  Now the kernels are
+    dispatched once (empty) before the planner's large allocations and the planner leaves a reserve: creating planners
+    until the device is full must end in PP_ERR_CAPACITY (-4) with a message, and every planner created must still search."""
+    import pathplanning_amd as pa
+    from pathplanning_amd._lib import PPError
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    planners = []
+    err = None
+    for k in range(64):
+        try:
+            p = pa.HybridAStarBatch(val, pa.HybridAStarSearchParameters(), max_batch=4096, max_nodes=81920, search_rows=2048)
+        except PPError as e:
+            err = e
+            break
+        planners.append(p)
+    assert err is not None, "64 throughput-sized planners cannot fit in 288 GB"
+    assert err.code == -4 and "reserved" in str(err), (err.code, str(err))
+    assert len(planners) >= 2
+    rng = np.random.RandomState(3)
+    starts = valid_random_poses(rng, w, 80)
+    goals = valid_random_poses(rng, w, 80)
+    seeds = np.arange(80, dtype=np.uint64)
+    first = None
+    for p in (planners[0], planners[-1]):  # the last one was created with the least memory left
+        p.initialize()
+        res = p.search_batch(starts, goals, seeds)
+        got = [(r.status, r.n_expanded) for r in res]
+        first = first or got
+        assert got == first
+    for p in planners:
+        p.close()

@@ -1,0 +1,52 @@
+"""CPU-side gate on the register / scratch figures of the built gfx950 code objects (tools/kernel_resources.py reads the
+NT_AMDGPU_METADATA notes out of libpphip.so; no GPU needed).  Round 1 shipped k_wavefront with 328 B of scratch per lane
+(70 VGPR spills, 28 scratch stores per window cell inside the round loop); the figures below are what the restructured
+kernels need and must not creep back up.  The planner's allocation headroom (pp_planner.hip: kMaxPrivateBytes) has to
+cover the largest private segment of the kernels it launches."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# kernel -> (max scratch bytes per lane, max VGPR spills)
+LIMITS = {
+    "k_wavefront<false>": (136, 32),
+    "k_hybrid_search_rows": (408, 82),
+    "k_hybrid_search<false>": (112, 0),
+    "k_check_states": (0, 0),
+    "k_check_states_fused": (0, 0),
+    "k_check_arcs": (0, 0),
+    "k_check_segments": (0, 0),
+    "k_rollout": (0, 0),
+    "k_rs_solve": (0, 0),
+    "k_nonholo_build": (0, 0),
+    "k_knn": (0, 0),
+    "k_rrt": (0, 0),
+}
+
+
+def test_scratch_and_spills_do_not_regress():
+    from pathplanning_amd import build
+    import kernel_resources
+    lib = build.build(verbose=False)
+    res = {k["kernel"]: k for k in kernel_resources.resources(lib)}
+    for name, (scratch, spills) in LIMITS.items():
+        assert name in res, (name, sorted(res))
+        k = res[name]
+        assert k["scratch_bytes_per_lane"] <= scratch, (name, k)
+        assert k["vgpr_spill"] <= spills, (name, k)
+    # the wavefront kernel must keep two workgroups of eight waves per CU: <= 128 VGPRs, <= 80 KiB LDS
+    assert res["k_wavefront<false>"]["vgpr"] <= 128 and res["k_wavefront<false>"]["lds_bytes"] <= 80 * 1024
+
+
+def test_planner_headroom_covers_the_largest_private_segment():
+    from pathplanning_amd import build
+    import kernel_resources
+    lib = build.build(verbose=False)
+    res = {k["kernel"]: k for k in kernel_resources.resources(lib)}
+    src = open(os.path.join(ROOT, "pathplanning_amd", "csrc", "pp_planner.hip")).read()
+    reserve = int(re.search(r"constexpr size_t kMaxPrivateBytes = (\d+);", src).group(1))
+    launched = [k for n, k in res.items() if n.startswith(("k_wavefront", "k_hybrid_search"))]
+    assert launched and reserve >= max(k["scratch_bytes_per_lane"] for k in launched)
