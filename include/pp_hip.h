@@ -71,6 +71,10 @@ int pp_map_create(pp_ctx* ctx, const pp_map_desc* desc, pp_map** out);
 int pp_map_destroy(pp_map* map);
 /* int32 squared distances to the nearest obstacle, INT_MAX = none (gvd.cpp:21). */
 int pp_map_upload_dist2(pp_map* map, const int32_t* d2_host);
+/* The same grid as the reference's accessor returns it: float distance in metres,
+ * ObstacleDistanceMap::GetDistanceToNearestObstacle(row, col) = sqrt(d2) * resolution (gvd.h:38).  Either upload
+ * serves; this one needs no access to the private int grid and loses nothing for INT_MAX / d2 > 2^24 cells. */
+int pp_map_upload_distance(pp_map* map, const float* distance_host);
 /* int32 occupancy, >= 0 occupied, < 0 free (obstacle_list_occupancy_map.cpp:63-69). */
 int pp_map_upload_occupancy(pp_map* map, const int32_t* occ_host);
 /* float Voronoi-field potential, GVD::GetPathCost (gvd.h:160-162). */
@@ -135,6 +139,41 @@ int pp_rs_solve_dev(pp_ctx* ctx, int64_t n, const double* from_dev, const double
 	float forward_cost, float switch_cost, int32_t* word_dev, double* tuv_dev, float* cost_dev, double* seg_length_dev);
 int pp_rs_solve(pp_ctx* ctx, int64_t n, const double* from_host, const double* to_host, double min_turning_radius, float reverse_cost,
 	float forward_cost, float switch_cost, int32_t* word_host, double* tuv_host, float* cost_host, double* seg_length_host);
+
+/* ---- a7: PathReedsShepp as a value (paths/path_reeds_shepp.{h,cpp}) ---------
+ * What the reference's object holds: m_init, m_final, the five ReedsShepp::Motion slots of its PathSegment
+ * (geometry/reeds_shepp.h:54-67: steer, direction, normalised length; +inf / NoMotion = unused slot),
+ * m_minTurningRadius and m_length (metres; after Truncate it is scaled by the ratio and no longer the sum of the slots).
+ * steer: 0 Left, 1 Straight, 2 Right (paths/path.h:10-14); direction: 0 Forward, 1 Backward, 2 NoMotion (:16-20). */
+typedef struct pp_rs_path {
+	double start[3];
+	double final_pose[3];
+	double motion_length[5];
+	int8_t steer[5];
+	int8_t direction[5];
+	int8_t reserved[6];
+	double min_turning_radius;
+	double length;
+	float cost;   /* pp_rs_connect: PathSegment::ComputeCost of the chosen word (float, as the reference compares it) */
+	int32_t word; /* pp_rs_connect: PathWords index, -1 = NoPath; carried along otherwise */
+} pp_rs_path;
+
+/* PathConnectionReedsShepp::Connect (path_reeds_shepp.cpp:174-179): GetOptimalPath + the PathReedsShepp constructor
+ * (m_final = Interpolate(1.0)), one path per (from, to) pair. */
+int pp_rs_connect(pp_ctx* ctx, int64_t n, const double* from_host, const double* to_host, double min_turning_radius, float reverse_cost,
+	float forward_cost, float switch_cost, pp_rs_path* paths_host);
+/* PathReedsShepp::Interpolate (:12-47) and ::GetDirection (:155-167) of path i at ratio_host[i]; either output may be NULL. */
+int pp_rs_path_interpolate(pp_ctx* ctx, int64_t n, const pp_rs_path* paths_host, const double* ratio_host, double* pose_host, int32_t* direction_host);
+/* PathReedsShepp::Truncate (:49-93) in place, INCLUDING the reference's wrong-slot reset when q11 != 0 (SURVEY
+ * Appendix A Q11: truncating inside motion i < 4 invalidates motion i itself); q11 == 0 drops the later motions instead. */
+int pp_rs_path_truncate(pp_ctx* ctx, int64_t n, pp_rs_path* paths_host, const double* ratio_host, int32_t q11);
+/* PathReedsShepp::GetCuspPointRatios (:95-121): ascending, no duplicates; ratios_host is [n][4], count_host[i] <= 4. */
+int pp_rs_path_cusps(pp_ctx* ctx, int64_t n, const pp_rs_path* paths_host, double* ratios_host, int32_t* count_host);
+/* StateValidatorOccupancyMap::IsPathValid (state_validator_occupancy_map.cpp:28-71) over Reeds-Shepp paths. */
+int pp_check_rs_paths_dev(pp_map* map, int64_t n, const pp_rs_path* paths_dev, uint8_t* valid_dev, float* last_ratio_dev);
+int pp_check_rs_paths(pp_map* map, int64_t n, const pp_rs_path* paths_host, uint8_t* valid_host, float* last_ratio_host);
+/* ... and over PathSE2 (paths/path_se2.cpp:5-22: position and heading interpolated linearly, length = |to - from|). */
+int pp_check_se2_paths(pp_map* map, int64_t n, const double* from_host, const double* to_host, uint8_t* valid_host, float* last_ratio_host);
 
 /* ---- a10: NonHolonomicHeuristic::Build (algo/heuristics.cpp:36-76) ---------
  * dims = {nX, nY, nAngular}; table[(i*nY + j)*nAngular + k]. */

@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE ONLY -- C entry points of the CPU oracle for ctypes.
 // See ppo_geometry.hpp for the scope / parity-pinning statement.
+#include <cstring>
 #include "ppo_search.hpp"
 
 #include <chrono>
@@ -262,6 +263,126 @@ int ppo_rs_path_valid(void* wv, const double* start, int word, const double* tuv
 	auto seg = rs::GetPath(word, tuv[0], tuv[1], tuv[2]);
 	PathReedsShepp path(P3raw(start), seg, rmin);
 	return ((World*)wv)->IsPathValid(path) ? 1 : 0;
+}
+
+// --------------------------------------------- PathReedsShepp as a record ----
+// Same 128-byte layout as the product ABI's pp_rs_path (include/pp_hip.h), restated here because the oracle shares no
+// header with the product: m_init, m_final, the five Motion slots, m_minTurningRadius, m_length, cost / word of Connect.
+struct PpoRsPath {
+	double start[3];
+	double finalPose[3];
+	double motionLength[5];
+	int8_t steer[5];
+	int8_t direction[5];
+	int8_t reserved[6];
+	double rmin;
+	double length;
+	float cost;
+	int32_t word;
+};
+static_assert(sizeof(PpoRsPath) == 128, "record layout");
+static PathReedsShepp FromRecord(const PpoRsPath& r)
+{
+	rs::PathSegment seg;
+	for (int i = 0; i < rs::kNumMotion; i++) {
+		seg.motions[i].steer = (Steer)r.steer[i];
+		seg.motions[i].direction = (Direction)r.direction[i];
+		seg.motions[i].length = r.motionLength[i];
+	}
+	PathReedsShepp p(Pose2d::Raw(r.start[0], r.start[1], r.start[2]), seg, r.rmin);
+	p.length = r.length; // a truncated path: m_length is no longer the sum of the slots
+	p.final = Pose2d::Raw(r.finalPose[0], r.finalPose[1], r.finalPose[2]);
+	return p;
+}
+static void ToRecord(const PathReedsShepp& p, PpoRsPath& r)
+{
+	r.start[0] = p.init.x, r.start[1] = p.init.y, r.start[2] = p.init.theta;
+	r.finalPose[0] = p.final.x, r.finalPose[1] = p.final.y, r.finalPose[2] = p.final.theta;
+	for (int i = 0; i < rs::kNumMotion; i++) {
+		r.motionLength[i] = p.segment.motions[i].length;
+		r.steer[i] = (int8_t)p.segment.motions[i].steer;
+		r.direction[i] = (int8_t)p.segment.motions[i].direction;
+	}
+	r.rmin = p.minTurningRadius;
+	r.length = p.length;
+}
+/// PathConnectionReedsShepp::Connect, paths/path_reeds_shepp.cpp:174-179
+void ppo_rs_connect(int64_t n, const double* from, const double* to, double rmin, float rev, float fwd, float sw, PpoRsPath* out)
+{
+	for (int64_t i = 0; i < n; i++) {
+		int w = -1;
+		double t3[3] = { 0, 0, 0 };
+		auto seg = rs::GetOptimalPath(P3(from + 3 * i), P3(to + 3 * i), rmin, rev, fwd, sw, &w, t3);
+		PathReedsShepp p(P3(from + 3 * i), seg, rmin);
+		std::memset(&out[i], 0, sizeof(PpoRsPath));
+		ToRecord(p, out[i]);
+		out[i].cost = seg.ComputeCost(rmin, rev, fwd, sw);
+		out[i].word = w;
+	}
+}
+void ppo_rs_path_interpolate(int64_t n, const PpoRsPath* paths, const double* ratio, double* pose, int32_t* direction)
+{
+	for (int64_t i = 0; i < n; i++) {
+		PathReedsShepp p = FromRecord(paths[i]);
+		Pose2d s = p.Interpolate(ratio[i]);
+		pose[3 * i] = s.x, pose[3 * i + 1] = s.y, pose[3 * i + 2] = s.theta;
+		direction[i] = (int32_t)p.GetDirection(ratio[i]);
+	}
+}
+void ppo_rs_path_truncate(int64_t n, PpoRsPath* paths, const double* ratio)
+{
+	for (int64_t i = 0; i < n; i++) {
+		PathReedsShepp p = FromRecord(paths[i]);
+		p.Truncate(ratio[i]);
+		ToRecord(p, paths[i]);
+	}
+}
+void ppo_rs_path_cusps(int64_t n, const PpoRsPath* paths, double* ratios, int32_t* count)
+{
+	for (int64_t i = 0; i < n; i++) {
+		PathReedsShepp p = FromRecord(paths[i]);
+		auto c = p.GetCuspPointRatios();
+		int k = 0;
+		for (double r : c)
+			if (k < 4)
+				ratios[4 * i + k++] = r;
+		count[i] = (int32_t)c.size();
+		for (; k < 4; k++)
+			ratios[4 * i + k] = 0.0;
+	}
+}
+void ppo_rs_paths_valid(void* wv, int64_t n, const PpoRsPath* paths, uint8_t* valid, float* last)
+{
+	World* w = (World*)wv;
+	for (int64_t i = 0; i < n; i++) {
+		PathReedsShepp p = FromRecord(paths[i]);
+		float l = -1.0f;
+		valid[i] = w->IsPathValid(p, &l) ? 1 : 0;
+		last[i] = l;
+	}
+}
+/// PathSE2, paths/path_se2.cpp:5-22
+struct PathSE2Line {
+	Pose2d init, final;
+	double length = 0.0;
+	Pose2d Interpolate(double ratio) const
+	{
+		// members assigned directly (path_se2.cpp:13-15): theta is not wrapped
+		return Pose2d::Raw((1 - ratio) * init.x + ratio * final.x, (1 - ratio) * init.y + ratio * final.y, (1 - ratio) * init.theta + ratio * final.theta);
+	}
+};
+void ppo_se2_paths_valid(void* wv, int64_t n, const double* from, const double* to, uint8_t* valid, float* last)
+{
+	World* w = (World*)wv;
+	for (int64_t i = 0; i < n; i++) {
+		PathSE2Line p;
+		p.init = P3(from + 3 * i);
+		p.final = P3(to + 3 * i);
+		p.length = Norm(p.final.x - p.init.x, p.final.y - p.init.y);
+		float l = -1.0f;
+		valid[i] = w->IsPathValid(p, &l) ? 1 : 0;
+		last[i] = l;
+	}
 }
 
 // ----------------------------------------------------------- heuristics ----

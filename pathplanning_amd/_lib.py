@@ -48,6 +48,12 @@ class QueryResult(C.Structure):
                 ("n_rng_draws", C.c_int32), ("n_rs_attempts", C.c_int32), ("n_state_checks", C.c_int64), ("n_path_checks", C.c_int64)]
 
 
+# pp_rs_path (include/pp_hip.h): PathReedsShepp as a 128-byte record
+RS_PATH_DTYPE = np.dtype([("start", "<f8", 3), ("final_pose", "<f8", 3), ("motion_length", "<f8", 5), ("steer", "i1", 5), ("direction", "i1", 5),
+                          ("reserved", "i1", 6), ("min_turning_radius", "<f8"), ("length", "<f8"), ("cost", "<f4"), ("word", "<i4")])
+assert RS_PATH_DTYPE.itemsize == 128
+
+
 class RrtResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_nodes", C.c_int32), ("n_path", C.c_int32), ("iterations", C.c_int64),
                 ("n_knn_queries", C.c_int64), ("n_edge_checks", C.c_int64)]
@@ -96,6 +102,14 @@ def load():
     L.pp_check_segments_dev.argtypes = [vp, C.c_int64, vp, vp, vp]
     L.pp_rollout_children.argtypes = [vp, C.POINTER(HybridParams), C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     L.pp_rollout_children_dev.argtypes = [vp, C.POINTER(HybridParams), C.c_int32, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.pp_map_upload_distance.argtypes = [vp, vp]
+    L.pp_rs_connect.argtypes = [vp, C.c_int64, vp, vp, C.c_double, C.c_float, C.c_float, C.c_float, vp]
+    L.pp_rs_path_interpolate.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
+    L.pp_rs_path_truncate.argtypes = [vp, C.c_int64, vp, vp, C.c_int32]
+    L.pp_rs_path_cusps.argtypes = [vp, C.c_int64, vp, vp, vp]
+    L.pp_check_rs_paths.argtypes = [vp, C.c_int64, vp, vp, vp]
+    L.pp_check_rs_paths_dev.argtypes = [vp, C.c_int64, vp, vp, vp]
+    L.pp_check_se2_paths.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
     L.pp_rs_solve.argtypes = [vp, C.c_int64, vp, vp, C.c_double, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]
     L.pp_rs_solve_dev.argtypes = [vp, C.c_int64, vp, vp, C.c_double, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]
     L.pp_nonholo_dims.argtypes = [vp, vp, C.POINTER(HybridParams), vp, vp]

@@ -372,6 +372,89 @@ namespace rs {
 			}
 			return interp;
 		}
+		/// PathReedsShepp::Truncate, paths/path_reeds_shepp.cpp:49-93: returns m_final.  The reference means to drop the
+		/// motions behind the cut but resets `m_motions[i]` -- the motion that CONTAINS the cut -- instead of `[ii]` whenever
+		/// a later slot exists (i < 4); `q11` = true reproduces that, false drops the later ones.
+		PPD_INLINE Pose truncate(double ratio, bool q11)
+		{
+			const double totalLength = length;
+			Pose fin = init;
+			if (totalLength != 0) {
+				Pose interp = init;
+				double len = 0;
+				for (int i = 0; i < kNumMotion; i++) {
+					if (!motion_valid(seg, i))
+						break;
+					double motionLength = seg.len[i] * rmin;
+					if (motionLength == 0)
+						continue;
+					double motionRatio = (ratio * totalLength - len) / motionLength;
+					motionRatio = motionRatio < 1.0 ? motionRatio : 1.0;
+					if (seg.steer[i] == kStraight)
+						interp = straight(interp, seg.dir[i], seg.len[i] * motionRatio);
+					else
+						interp = turn(interp, seg.dir[i], seg.steer[i], seg.len[i] * motionRatio);
+					len += motionLength;
+					if (len >= ratio * totalLength) {
+						seg.len[i] *= motionRatio;
+						for (int ii = i + 1; ii < kNumMotion; ii++) {
+							const int k = q11 ? i : ii;
+							seg.len[k] = inf(); // ReedsShepp::Motion(): {steer (indeterminate, kept), NoMotion, +inf}
+							seg.dir[k] = (int8_t)kNoMotion;
+						}
+						break;
+					}
+				}
+				fin = interp;
+			}
+			length *= ratio;
+			return fin;
+		}
+		/// PathReedsShepp::GetDirection, paths/path_reeds_shepp.cpp:155-167
+		PPD_INLINE int direction(double ratio) const
+		{
+			if (length == 0)
+				return kNoMotion;
+			double len = 0;
+			for (int i = 0; i < kNumMotion; i++) {
+				if (!motion_valid(seg, i))
+					break;
+				len += seg.len[i] * rmin;
+				if (ratio * length <= len)
+					return seg.dir[i];
+			}
+			return kNoMotion;
+		}
+		/// PathReedsShepp::GetCuspPointRatios, paths/path_reeds_shepp.cpp:95-121: the std::set as a sorted array without
+		/// duplicates (at most 4 entries); returns the count
+		PPD_INLINE int cusps(double* out) const
+		{
+			int count = 0;
+			if (length == 0.0)
+				return 0;
+			int nm = 0; // PathSegment::GetNumMotions, reeds_shepp.cpp:458-467
+			while (nm < kNumMotion && motion_valid(seg, nm))
+				nm++;
+			double len = seg.len[0] * rmin;
+			for (int i = 1; i < nm; i++) {
+				const double ratio = len / length;
+				if (ratio > 1.0)
+					break;
+				if (seg.dir[i] != seg.dir[i - 1]) {
+					int pos = 0;
+					while (pos < count && out[pos] < ratio)
+						pos++;
+					if (!(pos < count && out[pos] == ratio)) {
+						for (int k = count; k > pos; k--)
+							out[k] = out[k - 1];
+						out[pos] = ratio;
+						count++;
+					}
+				}
+				len += seg.len[i] * rmin;
+			}
+			return count;
+		}
 	};
 
 	/// ReedsShepp::Solver::GetOptimalPath, reeds_shepp.cpp:654-683: one thread, all 48 words.

@@ -12,99 +12,10 @@
 // Everything computes on the GPU; constructing any of the HIP-backed classes without a device throws.
 #pragma once
 
-#include <array>
-#include <algorithm>
-#include <cmath>
-#include <cstdint>
-#include <cstdlib>
-#include <memory>
-#include <stdexcept>
-#include <string>
-#include <vector>
-
-#include "../../include/pp_hip.h"
+#include "types.hpp"
+#include "paths.hpp"
 
 namespace Planner {
-
-template <typename T>
-using Ref = std::shared_ptr<T>;
-template <typename T, typename... Args>
-Ref<T> makeRef(Args&&... args) { return std::make_shared<T>(std::forward<Args>(args)...); }
-
-enum Status { Success = 0, Failure = -1 }; // algo/path_planner.h:9-12
-enum class Direction { Forward, Backward, NoMotion }; // paths/path.h:16-20
-
-struct Point2d { // geometry/2dplane.h:11-14 (Eigen::Vector2d in the reference)
-	double v[2] = { 0.0, 0.0 };
-	Point2d() = default;
-	Point2d(double x, double y) { v[0] = x; v[1] = y; }
-	double& x() { return v[0]; }
-	double& y() { return v[1]; }
-	const double& x() const { return v[0]; }
-	const double& y() const { return v[1]; }
-	Point2d operator+(const Point2d& o) const { return { v[0] + o.v[0], v[1] + o.v[1] }; }
-	Point2d operator-(const Point2d& o) const { return { v[0] - o.v[0], v[1] - o.v[1] }; }
-	bool operator==(const Point2d& o) const { return v[0] == o.v[0] && v[1] == o.v[1]; }
-	bool operator!=(const Point2d& o) const { return !(*this == o); }
-	double norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1]); }
-};
-
-struct Pose2d { // geometry/2dplane.h:17-45: 3 contiguous doubles, constructors wrap theta
-	Point2d position;
-	double theta = 0.0;
-	Pose2d() = default;
-	Pose2d(const Point2d& p, double t) : position(p), theta(t) { theta = WrapTheta(); }
-	Pose2d(double x, double y, double t) : position(x, y), theta(t) { theta = WrapTheta(); }
-	double& x() { return position.x(); }
-	double& y() { return position.y(); }
-	const double& x() const { return position.x(); }
-	const double& y() const { return position.y(); }
-	double WrapTheta() const
-	{
-		double t = theta;
-		while (t > M_PI)
-			t -= 2 * M_PI;
-		while (t < -M_PI)
-			t += 2 * M_PI;
-		return t;
-	}
-	bool operator==(const Pose2d& o) const { return position == o.position && theta == o.theta; }
-	bool operator!=(const Pose2d& o) const { return !(*this == o); }
-};
-static_assert(sizeof(Pose2d) == 24, "Pose2d must be 3 contiguous doubles (the ABI's pose layout)");
-
-struct GridCellPosition { // utils/grid.h:8-22, utils/grid.cpp:6-66
-	int row = -1, col = -1;
-	GridCellPosition() = default;
-	GridCellPosition(int r, int c) : row(r), col(c) { }
-	bool IsValid() const { return row >= 0 && col >= 0; }
-	bool operator==(const GridCellPosition& o) const { return row == o.row && col == o.col; }
-	bool operator!=(const GridCellPosition& o) const { return !(*this == o); }
-	bool IsAdjacentTo(const GridCellPosition& o) const { return !(*this == o) && std::abs(row - o.row) <= 1 && std::abs(col - o.col) <= 1; }
-	bool IsDiagonalTo(const GridCellPosition& o) const { return row != o.row && col != o.col; }
-	/// in-grid 8-neighbours in the reference's enumeration order (grid.cpp:29-47):
-	/// the column-1 side (same row, row-1, row+1), the column+1 side (same order), then (row-1, col), (row+1, col)
-	std::vector<GridCellPosition> GetNeighbors(int rows, int columns) const
-	{
-		std::vector<GridCellPosition> out;
-		if (!IsValid())
-			return out;
-		out.reserve(8);
-		static const int kStep[8][2] = { { 0, -1 }, { -1, -1 }, { 1, -1 }, { 0, 1 }, { -1, 1 }, { 1, 1 }, { -1, 0 }, { 1, 0 } };
-		for (const auto& d : kStep) {
-			const int r = row + d[0], c = col + d[1];
-			if (r >= 0 && r < rows && c >= 0 && c < columns)
-				out.push_back({ r, c });
-		}
-		return out;
-	}
-};
-
-inline void ppCheck(int rc)
-{
-	if (rc != 0)
-		throw std::runtime_error(std::string("libpphip: ") + pp_last_error());
-}
 
 /// algo/path_planner.h:19-41
 template <typename Vertex>
@@ -147,26 +58,6 @@ public:
 	const std::array<Pose2d, 2> bounds;
 };
 
-/// One GPU context shared by the objects of a process (device 0 unless PP_DEVICE is set).
-class HipContext {
-public:
-	static pp_ctx* Get()
-	{
-		static HipContext instance;
-		return instance.m_ctx;
-	}
-private:
-	HipContext()
-	{
-		int dev = 0;
-		if (const char* e = std::getenv("PP_DEVICE"))
-			dev = std::atoi(e);
-		ppCheck(pp_ctx_create(dev, nullptr, &m_ctx));
-	}
-	~HipContext() { pp_ctx_destroy(m_ctx); }
-	pp_ctx* m_ctx = nullptr;
-};
-
 /// state_validator/occupancy_map.{h,cpp}: sizes + transforms + the three grids the path reads.
 /// Map authoring (shapes, brushfire) is outside this library: the grids are set by the caller.
 class OccupancyMap {
@@ -184,6 +75,7 @@ public:
 			throw std::invalid_argument("Invalid grid size: received " + std::to_string(m_rows) + " x " + std::to_string(m_columns)); // utils/grid.h:69-72
 		m_occupancy.assign((size_t)m_rows * m_columns, -1);
 		m_dist2.assign((size_t)m_rows * m_columns, INT32_MAX);
+		m_distance.assign((size_t)m_rows * m_columns, DistanceOf(INT32_MAX));
 		m_pathCost.assign((size_t)m_rows * m_columns, 0.0f);
 		m_version++;
 	}
@@ -210,10 +102,26 @@ public:
 	{
 		const size_t n = (size_t)m_rows * m_columns;
 		if (occupancy) m_occupancy.assign(occupancy, occupancy + n);
-		if (dist2) m_dist2.assign(dist2, dist2 + n);
+		if (dist2) {
+			m_dist2.assign(dist2, dist2 + n);
+			for (size_t i = 0; i < n; i++)
+				m_distance[i] = DistanceOf(dist2[i]);
+		}
 		if (pathCost) m_pathCost.assign(pathCost, pathCost + n);
 		m_version++;
 	}
+	/// The distance grid as the reference's accessor returns it (float metres): ObstacleDistanceMap::GetDistanceToNearestObstacle
+	/// for every cell, row-major.  Use this when only the accessor is reachable (m_distance is private in the reference).
+	void SetDistances(const float* distance)
+	{
+		m_distance.assign(distance, distance + (size_t)m_rows * m_columns);
+		m_version++;
+	}
+	/// gvd.h:38: `std::sqrt(m_distance[row][col]) * resolution` -- sqrt of the int in double, product in double, returned as float
+	float DistanceOf(int32_t d2) const { return (float)(std::sqrt((double)d2) * (double)resolution); }
+	float GetDistanceToNearestObstacle(int row, int col) const { return m_distance[(size_t)row * m_columns + col]; }
+	const std::vector<float>& Distance() const { return m_distance; }
+	Point2d WorldPositionToLocalPosition(const Point2d& p) const { return p - m_localOrigin; } // occupancy_map.h:185-188
 	const std::vector<int32_t>& Occupancy() const { return m_occupancy; }
 	const std::vector<int32_t>& Dist2() const { return m_dist2; }
 	const std::vector<float>& PathCost() const { return m_pathCost; }
@@ -224,7 +132,7 @@ protected:
 	int m_rows = -1, m_columns = -1;
 	Point2d m_localOrigin, m_localGridOrigin, m_worldGridOrigin;
 	std::vector<int32_t> m_occupancy, m_dist2;
-	std::vector<float> m_pathCost;
+	std::vector<float> m_pathCost, m_distance;
 	uint64_t m_version = 0;
 };
 
@@ -234,9 +142,33 @@ public:
 	explicit StateValidatorSE2Base(const Ref<StateSpaceSE2>& s) : m_stateSpace(s) { }
 	virtual ~StateValidatorSE2Base() = default;
 	virtual bool IsStateValid(const Pose2d& state) = 0;
+	/// `last`: ratio of the last valid sample along the path
+	virtual bool IsPathValid(const PathSE2Base& path, float* last = nullptr) = 0;
+	/// state_validator.h:30-37 as it was meant (the reference passes the float by value there, Appendix A Q18)
+	bool IsPathValid(const PathSE2Base& path, Pose2d* last)
+	{
+		float ratio = 0.0f;
+		const bool ok = IsPathValid(path, &ratio);
+		if (last)
+			*last = path.Interpolate(ratio);
+		return ok;
+	}
 	Ref<StateSpaceSE2>& GetStateSpace() { return m_stateSpace; }
 protected:
 	Ref<StateSpaceSE2> m_stateSpace;
+};
+
+/// state_validator/state_validator_free.h:9-31: bounds only, every path valid
+class StateValidatorSE2Free : public StateValidatorSE2Base {
+public:
+	explicit StateValidatorSE2Free(const Ref<StateSpaceSE2>& s) : StateValidatorSE2Base(s) { }
+	bool IsStateValid(const Pose2d& state) override { return m_stateSpace->ValidateBounds(state); }
+	bool IsPathValid(const PathSE2Base& /*path*/, float* last = nullptr) override
+	{
+		if (last)
+			*last = 1.0;
+		return true;
+	}
 };
 
 /// state_validator/state_validator_occupancy_map.{h,cpp}, GPU-backed.
@@ -279,6 +211,68 @@ public:
 			*last = l;
 		return v != 0;
 	}
+	/// state_validator_occupancy_map.cpp:28-71.  The reference's path types are validated on the GPU, whole march in one kernel:
+	/// PathConstantSteer -> pp_check_arcs, PathReedsShepp -> pp_check_rs_paths, PathSE2 -> pp_check_se2_paths.  A path type
+	/// defined by the caller (a C++ or Python subclass of Path) can only be sampled through its own virtual Interpolate on the
+	/// host, so for those the march runs here, sample by sample, over the host copy of the distance grid.
+	bool IsPathValid(const PathSE2Base& path, float* last = nullptr) override
+	{
+		uint8_t v = 0;
+		float l = 0.0f;
+		if (auto* arc = dynamic_cast<const PathConstantSteer*>(&path)) {
+			if (arc->GetModel()->RearToCenter() == 0.0) { // the device arc is the rear-axle model the planner uses (hybrid_a_star.cpp:19)
+				const double kappa = arc->GetModel()->Curvature(arc->GetSteeringAngle());
+				const double len = arc->GetLength();
+				const int32_t d = arc->GetDirection(0.0) == Direction::Backward ? 1 : 0;
+				ppCheck(pp_check_arcs(Device(), 1, &arc->GetInitialState().position.v[0], &kappa, &len, &d, &v, &l));
+				if (last)
+					*last = l;
+				return v != 0;
+			}
+		} else if (auto* rs = dynamic_cast<const PathReedsShepp*>(&path)) {
+			ppCheck(pp_check_rs_paths(Device(), 1, &rs->Record(), &v, &l));
+			if (last)
+				*last = l;
+			return v != 0;
+		} else if (auto* line = dynamic_cast<const PathSE2*>(&path)) {
+			ppCheck(pp_check_se2_paths(Device(), 1, &line->GetInitialState().position.v[0], &line->GetFinalState().position.v[0], &v, &l));
+			if (last)
+				*last = l;
+			return v != 0;
+		}
+		return MarchOnHost(path, last);
+	}
+	/// IsPathValid over many paths of one of the reference's types at once (one launch per type); `last` may be null
+	std::vector<uint8_t> IsPathValid(const std::vector<Ref<PathSE2Base>>& paths, std::vector<float>* last = nullptr)
+	{
+		std::vector<uint8_t> out(paths.size());
+		if (last)
+			last->assign(paths.size(), 0.0f);
+		std::vector<pp_rs_path> recs;
+		std::vector<size_t> recIdx;
+		for (size_t i = 0; i < paths.size(); i++) {
+			if (auto* rs = dynamic_cast<const PathReedsShepp*>(paths[i].get())) {
+				recs.push_back(rs->Record());
+				recIdx.push_back(i);
+			} else {
+				float l = 0.0f;
+				out[i] = IsPathValid(*paths[i], &l) ? 1 : 0;
+				if (last)
+					(*last)[i] = l;
+			}
+		}
+		if (!recs.empty()) {
+			std::vector<uint8_t> v(recs.size());
+			std::vector<float> l(recs.size());
+			ppCheck(pp_check_rs_paths(Device(), (int64_t)recs.size(), recs.data(), v.data(), l.data()));
+			for (size_t k = 0; k < recs.size(); k++) {
+				out[recIdx[k]] = v[k];
+				if (last)
+					(*last)[recIdx[k]] = l[k];
+			}
+		}
+		return out;
+	}
 	Ref<OccupancyMap>& GetOccupancyMap() { return m_map; }
 	/// device map set, (re)uploaded when the host grids or the tunables changed
 	pp_map* Device()
@@ -299,7 +293,7 @@ public:
 			m_uploaded = ~0ull;
 		}
 		if (m_uploaded != m_map->Version()) {
-			ppCheck(pp_map_upload_dist2(m_dev, m_map->Dist2().data()));
+			ppCheck(pp_map_upload_distance(m_dev, m_map->Distance().data()));
 			ppCheck(pp_map_upload_occupancy(m_dev, m_map->Occupancy().data()));
 			ppCheck(pp_map_upload_path_cost(m_dev, m_map->PathCost().data()));
 			m_uploaded = m_map->Version();
@@ -311,6 +305,43 @@ public:
 	float minSafeRadius = 1.0f;
 
 private:
+	/// the reference's loop, verbatim in structure, for caller-defined path types (see IsPathValid)
+	bool MarchOnHost(const PathSE2Base& path, float* last)
+	{
+		auto stateValid = [&](const Pose2d& state, float& distance) {
+			const Pose2d local(m_map->WorldPositionToLocalPosition(state.position), state.theta);
+			const GridCellPosition cell = m_map->WorldPositionToGridCell(state.position);
+			if (!m_stateSpace->ValidateBounds(local) || !m_map->IsInsideMap(cell))
+				return false;
+			distance = m_map->GetDistanceToNearestObstacle(cell.row, cell.col);
+			return distance >= minSafeRadius;
+		};
+		const auto& bounds = m_stateSpace->bounds;
+		const double pathLength = path.GetLength();
+		float distance = 0.0f;
+		if (pathLength == 0.0) {
+			if (last)
+				*last = 1.0f;
+			return stateValid(path.GetInitialState(), distance);
+		}
+		double lastValidLength = 0.0, length = 0.0;
+		while (length < pathLength) {
+			const Pose2d state = path.Interpolate(length / pathLength);
+			if (!stateValid(state, distance)) {
+				if (last)
+					*last = lastValidLength / pathLength;
+				return false;
+			}
+			lastValidLength = length;
+			const float distToMapBorder = std::min({ state.x() - bounds[0].x(), bounds[1].x() - state.x(), state.y() - bounds[0].y(), bounds[1].y() - state.y() });
+			float deltaLength = distance - minSafeRadius;
+			deltaLength = std::min(deltaLength, distToMapBorder);
+			length += std::max(deltaLength, minPathInterpolationDistance);
+		}
+		if (last)
+			*last = 1.0f;
+		return true;
+	}
 	Ref<OccupancyMap> m_map;
 	pp_map* m_dev = nullptr;
 	uint64_t m_uploaded = ~0ull;
@@ -383,6 +414,35 @@ public:
 		std::vector<Pose2d> out((size_t)m_last.n_path);
 		if (m_last.n_path > 0)
 			ppCheck(pp_planner_get_path(m_planner, 0, &out[0].position.v[0], nullptr, nullptr, nullptr, nullptr));
+		return out;
+	}
+	/// algo/hybrid_a_star.h:231: the solution as path objects, one per edge of the search tree (constant-steer arcs, then
+	/// possibly the Reeds-Shepp connection to the goal); empty when the search failed
+	std::vector<Ref<PathNonHolonomicSE2Base>> GetGraphSearchPath() const
+	{
+		std::vector<Ref<PathNonHolonomicSE2Base>> out;
+		const int n = m_last.n_path;
+		if (n < 2)
+			return out;
+		std::vector<Pose2d> poses((size_t)n);
+		std::vector<int32_t> kind((size_t)n), prim((size_t)n);
+		std::vector<double> length((size_t)n);
+		ppCheck(pp_planner_get_path(m_planner, 0, &poses[0].position.v[0], kind.data(), prim.data(), length.data(), nullptr));
+		auto model = makeRef<KinematicBicycleModel>(m_param.wheelbase, 0.0); // hybrid_a_star.cpp:19
+		// steering of primitive p = 2 * deltaIndex + direction, deltas {0, +d1, -d1, ...} (hybrid_a_star.cpp:21-28, 65-77)
+		const double deltaMax = model->GetSteeringAngleFromTurningRadius(m_param.minTurningRadius);
+		for (int i = 1; i < n; i++) {
+			if (kind[i] == 1) {
+				const int di = prim[i] / 2;
+				const double delta = di == 0 ? 0.0 : ((di + 1) / 2) / 2.0 * deltaMax * ((di & 1) ? 1.0 : -1.0);
+				out.push_back(makeRef<PathConstantSteer>(model, poses[i - 1], delta, length[i], (prim[i] & 1) ? Direction::Backward : Direction::Forward));
+			} else { // the analytic expansion: GetOptimalPath(parent, goal) with the planner's costs (hybrid_a_star.cpp:155-157)
+				pp_rs_path rec;
+				ppCheck(pp_rs_connect(HipContext::Get(), 1, &poses[i - 1].position.v[0], &m_goal.position.v[0], m_param.minTurningRadius, (float)m_param.reverseCostMultiplier,
+					(float)m_param.forwardCostMultiplier, (float)m_param.directionSwitchingCost, &rec));
+				out.push_back(makeRef<PathReedsShepp>(rec));
+			}
+		}
 		return out;
 	}
 	double GetGraphSearchOptimalCost() const { return m_last.status == 0 ? m_last.cost : INFINITY; }

@@ -22,6 +22,7 @@ PYBIND11_MODULE(pyplanning, m)
 	m.def("initialize", []() {}); // PP_INIT: logging / profiler singletons of the reference; nothing to set up here
 
 	py::enum_<Status>(m, "Status").value("SUCCESS", Status::Success).value("FAILURE", Status::Failure);
+	py::enum_<Steer>(m, "Steer").value("LEFT", Steer::Left).value("STRAIGHT", Steer::Straight).value("RIGHT", Steer::Right);
 	py::enum_<Direction>(m, "Direction").value("FORWARD", Direction::Forward).value("BACKWARD", Direction::Backward).value("NO_MOTION", Direction::NoMotion);
 
 	py::class_<Point2d>(m, "Point2d")
@@ -40,8 +41,63 @@ PYBIND11_MODULE(pyplanning, m)
 		.def_readwrite("theta", &Pose2d::theta)
 		.def("x", [](Pose2d& p) { return p.x(); })
 		.def("y", [](Pose2d& p) { return p.y(); })
+		.def(py::self + py::self)
+		.def(py::self - py::self)
 		.def(py::self == py::self)
 		.def(py::self != py::self);
+
+	// ---- paths (pyplanning.cpp:247-309) ----
+	struct PathSE2BaseWrapper : PathSE2Base {
+		using PathSE2Base::PathSE2Base;
+		Pose2d Interpolate(double ratio) const override { PYBIND11_OVERRIDE_PURE(Pose2d, PathSE2Base, Interpolate, ratio); }
+		void Truncate(double ratio) override { PYBIND11_OVERRIDE_PURE(void, PathSE2Base, Truncate, ratio); }
+	};
+	py::class_<PathSE2Base, Ref<PathSE2Base>, PathSE2BaseWrapper>(m, "PathSE2Base")
+		.def(py::init<>())
+		.def(py::init<Pose2d, double>(), py::arg("init"), py::arg("length") = 0.0)
+		.def("get_initial_state", &PathSE2Base::GetInitialState)
+		.def("get_final_state", &PathSE2Base::GetFinalState)
+		.def("interpolate", py::overload_cast<double>(&PathSE2Base::Interpolate, py::const_))
+		.def("interpolate", py::overload_cast<const std::vector<double>&>(&PathSE2Base::Interpolate, py::const_))
+		.def("truncate", &PathSE2Base::Truncate)
+		.def("get_length", &PathSE2Base::GetLength);
+	py::class_<PathSE2, Ref<PathSE2>, PathSE2Base>(m, "PathSE2").def(py::init<const Pose2d&, const Pose2d&>());
+	py::class_<PathNonHolonomicSE2Base, Ref<PathNonHolonomicSE2Base>, PathSE2Base>(m, "PathNonHolonomicSE2Base")
+		.def("get_direction", &PathNonHolonomicSE2Base::GetDirection)
+		.def("get_cusp_point_ratios", &PathNonHolonomicSE2Base::GetCuspPointRatios);
+	py::class_<PathReedsShepp, Ref<PathReedsShepp>, PathNonHolonomicSE2Base>(m, "PathReedsShepp")
+		.def("interpolate", py::overload_cast<double>(&PathReedsShepp::Interpolate, py::const_))
+		.def("interpolate", py::overload_cast<const std::vector<double>&>(&PathReedsShepp::Interpolate, py::const_))
+		.def_property("min_turning_radius", &PathReedsShepp::GetMinTurningRadius, nullptr)
+		.def_property_readonly("word", [](const PathReedsShepp& p) { return p.Record().word; })
+		.def_property_readonly("motions", [](const PathReedsShepp& p) {
+			py::list out;
+			const pp_rs_path& r = p.Record();
+			for (int i = 0; i < 5; i++)
+				if (r.motion_length[i] != INFINITY && r.direction[i] != 2)
+					out.append(py::make_tuple((Steer)r.steer[i], (Direction)r.direction[i], r.motion_length[i]));
+				else
+					break;
+			return out;
+		});
+	py::class_<KinematicBicycleModel, Ref<KinematicBicycleModel>>(m, "KinematicBicycleModel")
+		.def(py::init<double, double>(), py::arg("wheelbase") = 2.6, py::arg("rear_to_center") = 0.0)
+		.def("constant_steer", &KinematicBicycleModel::ConstantSteer, py::arg("from"), py::arg("steering"), py::arg("dist"), py::arg("direction") = Direction::Forward)
+		.def("get_steering_angle_from_turning_radius", &KinematicBicycleModel::GetSteeringAngleFromTurningRadius);
+	py::class_<PathConstantSteer, Ref<PathConstantSteer>, PathNonHolonomicSE2Base>(m, "PathConstantSteer")
+		.def(py::init<const Ref<KinematicBicycleModel>&, const Pose2d&, double, double, Direction>())
+		.def_property("steering", &PathConstantSteer::GetSteeringAngle, nullptr);
+	struct PathConnectionSE2BaseWrapper : PathConnectionSE2Base {
+		using PathConnectionSE2Base::PathConnectionSE2Base;
+		Ref<PathSE2Base> Connect(const Pose2d& from, const Pose2d& to) override { PYBIND11_OVERRIDE_PURE(Ref<PathSE2Base>, PathConnectionSE2Base, Connect, from, to); }
+	};
+	py::class_<PathConnectionSE2Base, Ref<PathConnectionSE2Base>, PathConnectionSE2BaseWrapper>(m, "PathConnectionSE2Base")
+		.def(py::init<>())
+		.def("connect", &PathConnectionSE2Base::Connect);
+	py::class_<PathConnectionSE2, Ref<PathConnectionSE2>, PathConnectionSE2Base>(m, "PathConnectionSE2").def(py::init<>());
+	py::class_<PathConnectionReedsShepp, Ref<PathConnectionReedsShepp>, PathConnectionSE2Base>(m, "PathConnectionReedsShepp")
+		.def(py::init<double, double, double, double>(), py::arg("min_turning_radius") = 1.0, py::arg("direction_switching_cost") = 0.0, py::arg("reverse_cost_multiplier") = 1.0,
+			py::arg("forward_cost_multiplier") = 1.0);
 
 	py::class_<GridCellPosition>(m, "GridCellPosition")
 		.def(py::init<>())
@@ -84,11 +140,33 @@ PYBIND11_MODULE(pyplanning, m)
 					throw std::invalid_argument("set_grids: arrays must be rows x columns");
 				map.SetGrids(occ.data(), d2.data(), pc.data());
 			},
-			py::arg("occupancy"), py::arg("dist2"), py::arg("path_cost"));
+			py::arg("occupancy"), py::arg("dist2"), py::arg("path_cost"))
+		.def("set_distances",
+			[](OccupancyMap& map, py::array_t<float, py::array::c_style | py::array::forcecast> d) {
+				if ((size_t)d.size() != (size_t)map.Rows() * map.Columns())
+					throw std::invalid_argument("set_distances: array must be rows x columns");
+				map.SetDistances(d.data());
+			},
+			py::arg("distance"))
+		.def("get_distance_to_nearest_obstacle", &OccupancyMap::GetDistanceToNearestObstacle);
 
-	py::class_<StateValidatorSE2Base, Ref<StateValidatorSE2Base>>(m, "StateValidatorSE2Base")
+	struct StateValidatorSE2BaseWrapper : StateValidatorSE2Base { // pyplanning.cpp:402-406 (whose IsPathValid trampoline dispatches to IsStateValid, Q18)
+		using StateValidatorSE2Base::StateValidatorSE2Base;
+		bool IsStateValid(const Pose2d& a) override { PYBIND11_OVERRIDE_PURE(bool, StateValidatorSE2Base, IsStateValid, a); }
+		bool IsPathValid(const PathSE2Base& a, float* b) override { PYBIND11_OVERRIDE_PURE(bool, StateValidatorSE2Base, IsPathValid, a, b); }
+	};
+	py::class_<StateValidatorSE2Base, Ref<StateValidatorSE2Base>, StateValidatorSE2BaseWrapper>(m, "StateValidatorSE2Base")
+		.def(py::init<const Ref<StateSpaceSE2>&>())
 		.def("is_state_valid", &StateValidatorSE2Base::IsStateValid)
+		.def("is_path_valid", [](StateValidatorSE2Base& v, const PathSE2Base& path) { return v.IsPathValid(path, (float*)nullptr); })
+		.def("is_path_valid_with_ratio",
+			[](StateValidatorSE2Base& v, const PathSE2Base& path) {
+				float last = 0.0f;
+				const bool ok = v.IsPathValid(path, &last);
+				return py::make_tuple(ok, last);
+			})
 		.def_property("state_space", &StateValidatorSE2Base::GetStateSpace, nullptr);
+	py::class_<StateValidatorSE2Free, Ref<StateValidatorSE2Free>, StateValidatorSE2Base>(m, "StateValidatorSE2Free").def(py::init<const Ref<StateSpaceSE2>&>());
 
 	py::class_<StateValidatorOccupancyMap, Ref<StateValidatorOccupancyMap>, StateValidatorSE2Base>(m, "StateValidatorOccupancyMap")
 		.def(py::init<const Ref<StateSpaceSE2>&, const Ref<OccupancyMap>&>())
@@ -147,6 +225,7 @@ PYBIND11_MODULE(pyplanning, m)
 		.def_readwrite("path_interpolation", &HybridAStar::pathInterpolation)
 		.def("get_stats", &HybridAStar::GetStats)
 		.def("get_graph_search_optimal_cost", &HybridAStar::GetGraphSearchOptimalCost)
+		.def("get_graph_search_path", &HybridAStar::GetGraphSearchPath)
 		.def("get_search_parameters", &HybridAStar::GetSearchParameters)
 		.def("set_seed", &HybridAStar::SetSeed)
 		.def("search_batch",

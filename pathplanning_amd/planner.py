@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import HybridParams, MapDesc, QueryResult, check, ptr
+from ._lib import RS_PATH_DTYPE, HybridParams, MapDesc, QueryResult, check, ptr
 
 
 class Status:
@@ -117,6 +117,12 @@ class OccupancyMapSet:
         assert d2.shape == (self.rows, self.cols)
         check(self.lib.pp_map_upload_dist2(self.h, ptr(d2)))
 
+    def upload_distance(self, dist):
+        """float distance grid in metres, as ObstacleDistanceMap::GetDistanceToNearestObstacle returns it (gvd.h:38)"""
+        dist = np.ascontiguousarray(dist, dtype=np.float32)
+        assert dist.shape == (self.rows, self.cols)
+        check(self.lib.pp_map_upload_distance(self.h, ptr(dist)))
+
     def upload_occupancy(self, occ):
         occ = np.ascontiguousarray(occ, dtype=np.int32)
         assert occ.shape == (self.rows, self.cols)
@@ -210,6 +216,22 @@ class StateValidatorOccupancyMap:
         check(self.lib.pp_check_segments(self.map.h, len(a), ptr(a), ptr(b), ptr(valid)))
         return valid.astype(bool)
 
+    def is_rs_path_valid(self, paths):
+        """IsPathValid over Reeds-Shepp paths (records of RS_PATH_DTYPE, e.g. from ReedsSheppPaths.connect).  Returns (valid, last)."""
+        p = np.ascontiguousarray(paths, dtype=RS_PATH_DTYPE).reshape(-1)
+        valid = np.empty(len(p), dtype=np.uint8)
+        last = np.empty(len(p), dtype=np.float32)
+        check(self.lib.pp_check_rs_paths(self.map.h, len(p), ptr(p), ptr(valid), ptr(last)))
+        return valid.astype(bool), last
+
+    def is_se2_path_valid(self, start, end):
+        """IsPathValid over PathSE2 (paths/path_se2.cpp: linear in position and heading).  Returns (valid, last)."""
+        a, b = _f64(start, 3), _f64(end, 3)
+        valid = np.empty(len(a), dtype=np.uint8)
+        last = np.empty(len(a), dtype=np.float32)
+        check(self.lib.pp_check_se2_paths(self.map.h, len(a), ptr(a), ptr(b), ptr(valid), ptr(last)))
+        return valid.astype(bool), last
+
     def count_valid_fused(self, n, seed, count_tensor):
         check(self.lib.pp_check_states_fused_dev(self.map.h, int(n), C.c_uint64(seed), _dev_ptr(count_tensor)))
 
@@ -275,6 +297,42 @@ class ReedsSheppSolver:
         check(self.lib.pp_rs_solve(self.ctx.h, n, ptr(a), ptr(b), C.c_double(min_turning_radius), C.c_float(reverse_cost), C.c_float(forward_cost),
                                    C.c_float(switch_cost), ptr(word), ptr(tuv), ptr(cost), ptr(seg)))
         return word, tuv, cost, seg
+
+
+class ReedsSheppPaths:
+    """PathReedsShepp / PathConnectionReedsShepp as batches of 128-byte records (paths/path_reeds_shepp.{h,cpp}): connect,
+    interpolate (+ get_direction), truncate (with the reference's Q11 slot reset), get_cusp_point_ratios -- all on the device."""
+
+    def __init__(self, ctx, min_turning_radius=1.0, direction_switching_cost=0.0, reverse_cost_multiplier=1.0, forward_cost_multiplier=1.0):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.rmin, self.sw, self.rev, self.fwd = min_turning_radius, direction_switching_cost, reverse_cost_multiplier, forward_cost_multiplier
+
+    def connect(self, start, goal):
+        a, b = _f64(start, 3), _f64(goal, 3)
+        out = np.zeros(len(a), dtype=RS_PATH_DTYPE)
+        check(self.lib.pp_rs_connect(self.ctx.h, len(a), ptr(a), ptr(b), C.c_double(self.rmin), C.c_float(self.rev), C.c_float(self.fwd), C.c_float(self.sw), ptr(out)))
+        return out
+
+    def interpolate(self, paths, ratios):
+        p = np.ascontiguousarray(paths, dtype=RS_PATH_DTYPE).reshape(-1)
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(ratios, dtype=np.float64), len(p)))
+        pose = np.empty((len(p), 3))
+        direction = np.empty(len(p), dtype=np.int32)
+        check(self.lib.pp_rs_path_interpolate(self.ctx.h, len(p), ptr(p), ptr(r), ptr(pose), ptr(direction)))
+        return pose, direction
+
+    def truncate(self, paths, ratios, q11=True):
+        p = np.ascontiguousarray(paths, dtype=RS_PATH_DTYPE).reshape(-1).copy()
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(ratios, dtype=np.float64), len(p)))
+        check(self.lib.pp_rs_path_truncate(self.ctx.h, len(p), ptr(p), ptr(r), int(bool(q11))))
+        return p
+
+    def get_cusp_point_ratios(self, paths):
+        p = np.ascontiguousarray(paths, dtype=RS_PATH_DTYPE).reshape(-1)
+        ratios = np.empty((len(p), 4))
+        count = np.empty(len(p), dtype=np.int32)
+        check(self.lib.pp_rs_path_cusps(self.ctx.h, len(p), ptr(p), ptr(ratios), ptr(count)))
+        return [ratios[i, :count[i]].copy() for i in range(len(p))]
 
 
 class NonHolonomicHeuristic:

@@ -67,10 +67,50 @@ static void TestRRT()
 	std::printf("rrt*: %d/4 seeds reached the goal\n", ok);
 }
 
+// planner/tests/test_reeds_shepp.cpp:7-27 (the checker, on a few of its vectors) through PathConnectionReedsShepp, and the
+// generic IsPathValid(const Path&, float*) of the validator interface over each path type of the reference.
+static void TestPaths()
+{
+	std::array<Pose2d, 2> bounds = { Pose2d(-10, -10, -M_PI), Pose2d(10, 10, M_PI) };
+	Ref<StateSpaceSE2> stateSpace = makeRef<StateSpaceSE2>(bounds);
+	Ref<OccupancyMap> map = makeRef<OccupancyMap>(0.1f);
+	Ref<StateValidatorOccupancyMap> validator = makeRef<StateValidatorOccupancyMap>(stateSpace, map);
+	PathConnectionReedsShepp connection(1.0);
+	const Pose2d starts[3] = { Pose2d(0, 0, 0), Pose2d(1, -2, 0.5), Pose2d(-3, 2, -2.0) };
+	const Pose2d goals[3] = { Pose2d(4, 4, M_PI / 2), Pose2d(-2, 3, -1.0), Pose2d(0.5, 0.25, 3.0) };
+	for (int i = 0; i < 3; i++) {
+		Ref<PathSE2Base> path = connection.Connect(starts[i], goals[i]);
+		const Pose2d& end = path->GetFinalState();
+		assert((end.position - goals[i].position).norm() < 1e-6); // test_reeds_shepp.cpp:20-22
+		assert(std::fabs(Pose2d(0, 0, end.theta - goals[i].theta).theta) < 1e-6);
+		assert(path->GetLength() > 0);
+		float last = -1.0f;
+		assert(validator->IsPathValid(*path, &last) && last == 1.0f); // free map: valid all the way
+		auto* rs = dynamic_cast<PathReedsShepp*>(path.get());
+		assert(rs && rs->GetDirection(0.0) != Direction::NoMotion);
+		const double before = rs->GetLength();
+		rs->Truncate(0.5);
+		assert(std::fabs(rs->GetLength() - 0.5 * before) < 1e-12);
+	}
+	// a path that leaves the bounds is cut where the last valid sample was
+	PathSE2 out(Pose2d(0, 0, 0), Pose2d(20, 0, 0));
+	float last = -1.0f;
+	assert(!validator->IsPathValid(out, &last) && last > 0.3f && last <= 0.5f);
+	Pose2d lastState;
+	assert(!static_cast<StateValidatorSE2Base&>(*validator).IsPathValid(out, &lastState) && lastState.x() <= 10.0 && lastState.x() > 6.0);
+	auto model = makeRef<KinematicBicycleModel>(2.6, 0.0);
+	PathConstantSteer arc(model, Pose2d(0, 0, 0), 0.3, 3.0, Direction::Forward);
+	assert(validator->IsPathValid(arc, &last) && last == 1.0f);
+	StateValidatorSE2Free freeValidator(stateSpace);
+	assert(freeValidator.IsPathValid(out, &last) && last == 1.0f);
+	std::printf("paths: Reeds-Shepp connections reach their goals, IsPathValid over RS / SE2 / constant-steer paths\n");
+}
+
 int main()
 {
 	TestHybridAStar();
 	TestRRT();
+	TestPaths();
 	std::printf("plugin tests ok\n");
 	return 0;
 }

@@ -246,6 +246,64 @@ def rs_interpolate(start, word, tuv, rmin, ratios):
     return out
 
 
+RS_PATH_DTYPE = np.dtype([("start", "<f8", 3), ("final_pose", "<f8", 3), ("motion_length", "<f8", 5), ("steer", "i1", 5), ("direction", "i1", 5),
+                          ("reserved", "i1", 6), ("min_turning_radius", "<f8"), ("length", "<f8"), ("cost", "<f4"), ("word", "<i4")])
+
+
+def _vp(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def rs_connect(starts, goals, rmin, rev=1.0, fwd=1.0, sw=0.0):
+    """PathConnectionReedsShepp::Connect -> records (PathReedsShepp as data)."""
+    a = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
+    b = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(len(a), dtype=RS_PATH_DTYPE)
+    lib().ppo_rs_connect(C.c_int64(len(a)), dptr(a), dptr(b), C.c_double(rmin), C.c_float(rev), C.c_float(fwd), C.c_float(sw), _vp(out))
+    return out
+
+
+def rs_path_interpolate(paths, ratios):
+    p = np.ascontiguousarray(paths, dtype=RS_PATH_DTYPE).reshape(-1)
+    r = np.ascontiguousarray(np.broadcast_to(np.asarray(ratios, dtype=np.float64), len(p)))
+    pose = np.empty((len(p), 3))
+    direction = np.empty(len(p), dtype=np.int32)
+    lib().ppo_rs_path_interpolate(C.c_int64(len(p)), _vp(p), dptr(r), dptr(pose), iptr(direction))
+    return pose, direction
+
+
+def rs_path_truncate(paths, ratios):
+    p = np.ascontiguousarray(paths, dtype=RS_PATH_DTYPE).reshape(-1).copy()
+    r = np.ascontiguousarray(np.broadcast_to(np.asarray(ratios, dtype=np.float64), len(p)))
+    lib().ppo_rs_path_truncate(C.c_int64(len(p)), _vp(p), dptr(r))
+    return p
+
+
+def rs_path_cusps(paths):
+    p = np.ascontiguousarray(paths, dtype=RS_PATH_DTYPE).reshape(-1)
+    ratios = np.empty((len(p), 4))
+    count = np.empty(len(p), dtype=np.int32)
+    lib().ppo_rs_path_cusps(C.c_int64(len(p)), _vp(p), dptr(ratios), iptr(count))
+    return [ratios[i, :count[i]].copy() for i in range(len(p))]
+
+
+def rs_paths_valid(world, paths):
+    p = np.ascontiguousarray(paths, dtype=RS_PATH_DTYPE).reshape(-1)
+    valid = np.empty(len(p), dtype=np.uint8)
+    last = np.empty(len(p), dtype=np.float32)
+    lib().ppo_rs_paths_valid(world.h, C.c_int64(len(p)), _vp(p), u8ptr(valid), fptr(last))
+    return valid.astype(bool), last
+
+
+def se2_paths_valid(world, starts, goals):
+    a = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
+    b = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 3)
+    valid = np.empty(len(a), dtype=np.uint8)
+    last = np.empty(len(a), dtype=np.float32)
+    lib().ppo_se2_paths_valid(world.h, C.c_int64(len(a)), dptr(a), dptr(b), u8ptr(valid), fptr(last))
+    return valid.astype(bool), last
+
+
 def nonholo_build(lb, ub, params=None, threads=8):
     params = params_array() if params is None else params
     dims = np.zeros(3, dtype=np.int32)

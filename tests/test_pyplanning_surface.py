@@ -1,6 +1,7 @@
 """The pybind11 module keeps the reference's names for the hot-path surface
 (interfaces/python/src/pyplanning.cpp:42-122,208-237,320-327,337-357,402-421)."""
 import importlib
+import math
 import os
 import sys
 
@@ -86,3 +87,128 @@ def test_cpp_plugin_mirror_of_reference_tests():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "plugin tests ok" in out.stdout
+
+
+def test_path_value_types_on_the_host(nav):
+    """PathSE2 / PathConstantSteer / KinematicBicycleModel / Pose2d composition are plain host arithmetic in the mirror
+    (paths/path_se2.cpp, path_constant_steer.cpp, models/kinematic_bicycle_model.cpp, geometry/2dplane.h:47-79)."""
+    import oracle_lib as O
+    for name in ("Steer", "PathSE2Base", "PathSE2", "PathNonHolonomicSE2Base", "PathReedsShepp", "PathConstantSteer", "KinematicBicycleModel", "PathConnectionSE2Base",
+                 "PathConnectionSE2", "PathConnectionReedsShepp", "StateValidatorSE2Free", "AStarN2", "BidirectionalAStarN2", "AStarHeuristicFcnN2", "AStarStatePropagatorFcnN2",
+                 "PathPlannerN2Base"):
+        assert hasattr(nav, name), name
+    for meth in ("get_initial_state", "get_final_state", "interpolate", "truncate", "get_length"):
+        assert hasattr(nav.PathSE2Base, meth), meth
+    assert hasattr(nav.StateValidatorSE2Base, "is_path_valid") and hasattr(nav.HybridAStar, "get_graph_search_path")
+    a, b = nav.Pose2d(1.0, 2.0, 0.5), nav.Pose2d(4.0, 6.0, -1.0)
+    p = nav.PathSE2(a, b)
+    assert p.get_length() == 5.0
+    mid = p.interpolate(0.25)
+    assert (mid.x(), mid.y(), mid.theta) == (0.75 * 1.0 + 0.25 * 4.0, 0.75 * 2.0 + 0.25 * 6.0, 0.75 * 0.5 + 0.25 * -1.0)
+    p.truncate(0.5)
+    assert p.get_length() == 2.5 and p.get_final_state().x() == 2.5
+    # a + (b - a) == b
+    c = a + (b - a)
+    assert abs(c.x() - b.x()) < 1e-12 and abs(c.y() - b.y()) < 1e-12 and abs(c.theta - b.theta) < 1e-12
+    model = nav.KinematicBicycleModel(2.6, 0.0)
+    rng = np.random.RandomState(1)
+    frm = np.column_stack([rng.uniform(-5, 5, 200), rng.uniform(-5, 5, 200), rng.uniform(-3, 3, 200)])
+    steer = rng.uniform(-0.9, 0.9, 200)
+    steer[:5] = 0.0
+    dist = rng.uniform(0, 3, 200)
+    direc = rng.randint(0, 2, 200)
+    want = O.constant_steer(frm, steer, dist, direc)
+    for i in range(200):
+        arc = nav.PathConstantSteer(model, nav.Pose2d(*frm[i]), steer[i], dist[i], nav.Direction.BACKWARD if direc[i] else nav.Direction.FORWARD)
+        f = arc.get_final_state()
+        assert (f.x(), f.y(), f.theta) == tuple(want[i])  # same closed form, same libm: identical
+        assert arc.get_direction(0.3) == (nav.Direction.BACKWARD if direc[i] else nav.Direction.FORWARD)
+    ss = nav.StateSpaceSE2(nav.Pose2d(-10, -10, -np.pi), nav.Pose2d(10, 10, np.pi))
+    free = nav.StateValidatorSE2Free(ss)
+    assert free.is_state_valid(nav.Pose2d(0, 0, 0)) and not free.is_state_valid(nav.Pose2d(11, 0, 0))
+    assert free.is_path_valid(nav.PathSE2(a, nav.Pose2d(50, 50, 0)))  # state_validator_free.h:24-29: every path is valid
+
+
+@pytest.mark.gpu
+def test_generic_is_path_valid_and_graph_search_path_on_gpu(nav):
+    """StateValidator::IsPathValid(const Path&, float*) over every path type of the reference (validated on the GPU) and over
+    a path type defined in Python (sampled through its own interpolate, marched on the host copy of the distance grid);
+    PathConnectionReedsShepp / PathReedsShepp through the module; HybridAStar.get_graph_search_path()."""
+    import oracle_lib as O
+    from gpu_common import valid_random_poses
+    w = O.synthetic_world(256, 6, 3)
+    lb, ub = w.lb, w.ub
+    ss = nav.StateSpaceSE2(nav.Pose2d(lb[0], lb[1], lb[2]), nav.Pose2d(ub[0], ub[1], ub[2]))
+    m = nav.OccupancyMap(0.1)
+    val = nav.StateValidatorOccupancyMap(ss, m)
+    res = np.float64(np.float32(0.1))
+    m.set_grids(w.occ(), w.d2(), w.pathcost())
+    rng = np.random.RandomState(4)
+    a, b = valid_random_poses(rng, w, 120), valid_random_poses(rng, w, 120)
+    b[:60, :2] = a[:60, :2] + rng.uniform(-4, 4, (60, 2))
+    # Reeds-Shepp
+    conn = nav.PathConnectionReedsShepp(2.0, 0.0, 1.0, 1.0)
+    P = O.rs_connect(a, b, 2.0)
+    wv, wl = O.rs_paths_valid(w, P)
+    n_valid = 0
+    for i in range(len(a)):
+        path = conn.connect(nav.Pose2d(*a[i]), nav.Pose2d(*b[i]))
+        assert isinstance(path, nav.PathReedsShepp)
+        if path.word != P["word"][i]:
+            continue  # libm near-tie between two words (see test_gpu_paths.py)
+        assert abs(path.get_length() - P["length"][i]) < 1e-9
+        ok, last = val.is_path_valid_with_ratio(path)
+        assert ok == wv[i] and last == wl[i]
+        n_valid += ok
+        f = path.get_final_state()
+        assert abs(f.x() - P["final_pose"][i][0]) < 1e-9 and abs(f.theta - P["final_pose"][i][2]) < 1e-9
+        mid = path.interpolate(0.37)
+        wp, wd = O.rs_path_interpolate(P[i:i + 1], 0.37)
+        assert abs(mid.x() - wp[0][0]) < 1e-9 and int(path.get_direction(0.37)) == wd[0]
+        assert len(path.get_cusp_point_ratios()) == len(O.rs_path_cusps(P[i:i + 1])[0])
+    assert 5 < n_valid < 115
+    # PathSE2 on the GPU, and the same line as a Python-defined path type: the host march must agree with the kernel
+    sv, sl = O.se2_paths_valid(w, a, b)
+
+    class PyLine(nav.PathSE2Base):
+        def __init__(self, p, q):
+            super().__init__(p, math.hypot(q.x() - p.x(), q.y() - p.y()))
+            self.p, self.q = p, q
+
+        def Interpolate(self, r):
+            s = nav.Pose2d(0, 0, 0)
+            s.position = nav.Point2d((1 - r) * self.p.x() + r * self.q.x(), (1 - r) * self.p.y() + r * self.q.y())
+            s.theta = (1 - r) * self.p.theta + r * self.q.theta
+            return s
+
+    for i in range(len(a)):
+        p, q = nav.Pose2d(*a[i]), nav.Pose2d(*b[i])
+        ok, last = val.is_path_valid_with_ratio(nav.PathSE2(p, q))
+        assert ok == sv[i] and last == sl[i]
+        line = PyLine(p, q)
+        ok2, last2 = val.is_path_valid_with_ratio(line)
+        assert ok2 == sv[i] and last2 == sl[i]
+    # constant-steer arcs
+    model = nav.KinematicBicycleModel(2.6, 0.0)
+    steer = rng.uniform(-0.9, 0.9, len(a))
+    cv, cl = w.is_path_valid_csteer(a, steer, 3.0, 0)
+    for i in range(len(a)):
+        ok, last = val.is_path_valid_with_ratio(nav.PathConstantSteer(model, nav.Pose2d(*a[i]), steer[i], 3.0, nav.Direction.FORWARD))
+        assert ok == bool(cv[i]) and last == cl[i]
+    # the solution as path objects: edges chain up, lengths add up to the search's path, last edge is the RS connection
+    algo = nav.HybridAStar(nav.HybridAStarSearchParameters(), 4)
+    assert algo.initialize(val)
+    algo.set_init_state(nav.Pose2d(-10.0, -10.0, 0.0))
+    algo.set_goal_state(nav.Pose2d(10.0, 10.0, 0.0))
+    algo.set_seed(7)
+    assert algo.search_path() == nav.Status.SUCCESS
+    nodes = algo.get_path()
+    edges = algo.get_graph_search_path()
+    assert len(edges) == len(nodes) - 1
+    r = O.Hybrid(w).search([-10.0, -10.0, 0.0], [10.0, 10.0, 0.0], 7)
+    for k, e in enumerate(edges):
+        s0, s1 = e.get_initial_state(), e.get_final_state()
+        assert abs(s0.x() - nodes[k].x()) < 1e-12 and abs(s1.x() - nodes[k + 1].x()) < 1e-6 and abs(s1.y() - nodes[k + 1].y()) < 1e-6
+        assert abs(e.get_length() - r["path_length"][k + 1]) < 1e-6
+        assert val.is_path_valid(e)
+    assert isinstance(edges[-1], nav.PathReedsShepp) and isinstance(edges[0], nav.PathConstantSteer)
