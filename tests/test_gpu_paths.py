@@ -20,9 +20,11 @@ def random_pairs(rng, n, span=12.0):
 
 
 def same_records(got, want, tol=1e-9):
-    assert np.array_equal(got["steer"], want["steer"]) and np.array_equal(got["direction"], want["direction"])
+    assert np.array_equal(got["direction"], want["direction"])
     fin = np.isfinite(want["motion_length"])
     assert np.array_equal(np.isfinite(got["motion_length"]), fin)
+    used = fin & (want["direction"] != 2)  # Motion::steer of an unused slot is indeterminate in the reference (reeds_shepp.h:55)
+    assert np.array_equal(got["steer"][used], want["steer"][used])
     assert np.abs(got["motion_length"][fin] - want["motion_length"][fin]).max() < tol
     assert np.abs(got["final_pose"] - want["final_pose"]).max() < tol
     assert np.abs(got["length"] - want["length"]).max() < tol
