@@ -79,6 +79,31 @@ int pp_map_upload_distance(pp_map* map, const float* distance_host);
 int pp_map_upload_occupancy(pp_map* map, const int32_t* occ_host);
 /* float Voronoi-field potential, GVD::GetPathCost (gvd.h:160-162). */
 int pp_map_upload_path_cost(pp_map* map, const float* cost_host);
+/* ---- map authoring and field construction on the device ----
+ * Shape::RasterizeLine (state_validator/obstacle.cpp:7-61) for n segments given by their world end points (the caller rotates and
+ * translates the shape's vertices, PolygonShape::GetVerticesPosition, obstacle.cpp:86-93), writing `value` into every boundary
+ * cell: an obstacle id for ObstacleListOccupancyMap::AddObstacle, -1 for RemoveObstacle
+ * (obstacle_list_occupancy_map.cpp:29-61).  n_cells_out (may be NULL): cells written, with repeats. */
+int pp_map_rasterize_segments(pp_map* map, int32_t n_segments, const double* p0_xy_host, const double* p1_xy_host, int32_t value, int32_t* n_cells_out);
+/* The same walk with the cells listed instead of written (Shape::GetGridCellsPosition, Obstacle::GetBoundaryGridCellPosition):
+ * segment i fills cells_host[i * cap_per_segment * 2 ...] with (row, col) pairs in Bresenham order, count_host[i] of them.
+ * pp_map_set_cells writes `value` into listed cells (AddObstacle / RemoveObstacle for any Shape, also caller-defined ones). */
+int pp_rasterize_cells(pp_map* map, int32_t n_segments, const double* p0_xy_host, const double* p1_xy_host, int32_t cap_per_segment, int32_t* cells_host,
+	int32_t* count_host);
+int pp_map_set_cells(pp_map* map, int64_t n_cells, const int32_t* cells_host, int32_t value);
+int pp_map_download_occupancy(pp_map* map, int32_t* occ_host);
+/* GVD::Update (state_validator/gvd.cpp:294-301) from the device occupancy grid: squared obstacle distance + nearest obstacle cell
+ * (gvd.cpp:30-72), Voronoi edges (:105-131), squared distance to the nearest edge (:200-237), PathCostMap (:266-283; alpha,
+ * d_max: GVD::alpha / dMax, gvd.h:181); also refreshes what the validator reads.  The distance maps are the fixed point of the
+ * same 8-neighbour label propagation as the reference's brushfire, not its heap order: see pp_gvd.hip for what that means. */
+int pp_map_update_gvd(pp_map* map, float alpha, float d_max, int32_t* iterations_out);
+/* any pointer may be NULL; nearest_*: (row, col) per cell, (-1, -1) = none */
+int pp_map_download_gvd(pp_map* map, int32_t* d2_host, int32_t* nearest_obstacle_host, uint8_t* voronoi_edge_host, int32_t* voronoi_d2_host, int32_t* nearest_edge_host,
+	float* path_cost_host);
+/* PathCostMap::Update alone (gvd.cpp:266-283) over two squared-distance grids of the caller; keeps the result as the map's path
+ * cost and copies it out when path_cost_host != NULL. */
+int pp_path_cost_update(pp_map* map, const int32_t* obstacle_d2_host, const int32_t* voronoi_d2_host, float alpha, float d_max, float* path_cost_host);
+
 /* StateValidatorOccupancyMap::minSafeRadius / minPathInterpolationDistance
  * (state_validator/state_validator_occupancy_map.h:27-28). */
 int pp_map_set_validator(pp_map* map, float min_safe_radius, float min_path_interpolation_distance);

@@ -108,6 +108,10 @@ void map_release(pp_map* map)
 		(void)hipFree(map->occ8);
 	if (map->validBits)
 		(void)hipFree(map->validBits);
+	void* more[] = { map->occ32, map->obstLabel[0], map->obstLabel[1], map->voroLabel[0], map->voroLabel[1], map->voroD2, map->voroEdge, map->gvdFlag };
+	for (void* q : more)
+		if (q)
+			(void)hipFree(q);
 	pp_ctx* ctx = map->ctx;
 	delete map;
 	ctx_release(ctx);
@@ -265,12 +269,12 @@ int pp_map_upload_occupancy(pp_map* map, const int32_t* occ_host)
 	}
 	PP_HIP_TRY(hipSetDevice(map->ctx->device));
 	const size_t n = map->cells();
-	DevBuf tmp;
-	PP_HIP_TRY(tmp.alloc(n * sizeof(int32_t)));
+	if (!map->occ32) // kept: pp_map_update_gvd builds the distance / Voronoi / path-cost fields from it
+		PP_HIP_TRY(hipMalloc((void**)&map->occ32, n * sizeof(int32_t)));
 	if (!map->occ8)
 		PP_HIP_TRY(hipMalloc((void**)&map->occ8, n));
-	PP_HIP_TRY(hipMemcpyAsync(tmp.p, occ_host, n * sizeof(int32_t), hipMemcpyHostToDevice, map->ctx->stream));
-	PP_HIP_TRY(launch_occ_to_u8(map->ctx->stream, tmp.as<int32_t>(), map->occ8, (int64_t)n));
+	PP_HIP_TRY(hipMemcpyAsync(map->occ32, occ_host, n * sizeof(int32_t), hipMemcpyHostToDevice, map->ctx->stream));
+	PP_HIP_TRY(launch_occ_to_u8(map->ctx->stream, map->occ32, map->occ8, (int64_t)n));
 	PP_HIP_TRY(hipStreamSynchronize(map->ctx->stream));
 	return PP_OK;
 }

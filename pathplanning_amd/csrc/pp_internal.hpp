@@ -114,6 +114,14 @@ struct pp_map {
 	float* pathcost = nullptr;
 	uint8_t* occ8 = nullptr;
 	uint32_t* validBits = nullptr; // one bit per cell: dist >= minSafeRadius
+	// map authoring / field construction on the device (pp_gvd.hip)
+	int32_t* occ32 = nullptr;      // occupancy ids as the reference holds them (-1 free)
+	uint32_t* obstLabel[2] = { nullptr, nullptr }; // nearest obstacle cell (row << 16 | col), ping-pong
+	uint32_t* voroLabel[2] = { nullptr, nullptr }; // nearest Voronoi-edge cell
+	int obstResult = 0, voroResult = 0;            // which of the two holds the fixed point
+	int32_t* voroD2 = nullptr;
+	uint8_t* voroEdge = nullptr;
+	int32_t* gvdFlag = nullptr;
 	ppd::MapView view() const;
 	size_t cells() const { return (size_t)desc.rows * desc.cols; }
 };

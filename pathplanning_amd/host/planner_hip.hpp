@@ -58,12 +58,20 @@ public:
 	const std::array<Pose2d, 2> bounds;
 };
 
-/// state_validator/occupancy_map.{h,cpp}: sizes + transforms + the three grids the path reads.
-/// Map authoring (shapes, brushfire) is outside this library: the grids are set by the caller.
+/// state_validator/occupancy_map.{h,cpp}: sizes, transforms and the grids the path reads.  The map owns its device map set
+/// (pp_map).  The grids come from either side: set by the caller on the host (SetGrids / SetDistances, e.g. copied out of the
+/// reference's own GVD) and uploaded, or built on the device (obstacle outlines rasterised by ObstacleListOccupancyMap, fields by
+/// GVD::Update, map_authoring.hpp) and fetched back when a host accessor asks.
 class OccupancyMap {
 public:
 	explicit OccupancyMap(float res) : resolution(res) { }
-	virtual ~OccupancyMap() = default;
+	OccupancyMap(const OccupancyMap&) = delete;
+	OccupancyMap& operator=(const OccupancyMap&) = delete;
+	virtual ~OccupancyMap()
+	{
+		if (m_dev)
+			pp_map_destroy(m_dev);
+	}
 	void InitializeSize(float width, float height)
 	{
 		// occupancy_map.cpp:6-14
@@ -73,33 +81,59 @@ public:
 		m_columns = (int)std::ceil(height / resolution);
 		if (!(m_rows > 0 && m_columns > 0))
 			throw std::invalid_argument("Invalid grid size: received " + std::to_string(m_rows) + " x " + std::to_string(m_columns)); // utils/grid.h:69-72
+		m_width = width;
+		m_height = height;
 		m_occupancy.assign((size_t)m_rows * m_columns, -1);
 		m_dist2.assign((size_t)m_rows * m_columns, INT32_MAX);
 		m_distance.assign((size_t)m_rows * m_columns, DistanceOf(INT32_MAX));
 		m_pathCost.assign((size_t)m_rows * m_columns, 0.0f);
-		m_version++;
+		m_hostVersion++;
+		m_onDevice = false;
+		ResetDevice();
 	}
 	int Rows() const { return m_rows; }
 	int Columns() const { return m_columns; }
-	void SetPosition(const Point2d& p) { m_localOrigin = p; }
-	const Point2d& GetPosition() const { return m_localOrigin; }
-	virtual bool IsOccupied(const GridCellPosition& c) { return m_occupancy[(size_t)c.row * m_columns + c.col] >= 0; }
-	int GetOccupancyValue(int row, int col) const { return m_occupancy[(size_t)row * m_columns + col]; }
-	bool IsInsideMap(const GridCellPosition& c) const { return c.row >= 0 && c.row < m_rows && c.col >= 0 && c.col < m_columns; }
-	GridCellPosition WorldPositionToGridCell(const Point2d& p, bool bounded = true) const
+	/// occupancy_map.h:46 (the reference runs the obstacle brushfire here; the device fields are built by GVD::Update / BuildFields)
+	virtual void Update() { }
+	void SetPosition(const Point2d& p)
 	{
-		// occupancy_map.h:106-117,175-183
-		int row = (int)((p.x() - m_worldGridOrigin.x()) / resolution);
-		int col = (int)((p.y() - m_worldGridOrigin.y()) / resolution);
-		if (!bounded || IsInsideMap({ row, col }))
+		m_localOrigin = p;
+		m_worldGridOrigin = m_localOrigin + m_localGridOrigin;
+		ResetDevice();
+	}
+	const Point2d& GetPosition() const { return m_localOrigin; }
+	virtual bool IsOccupied(const GridCellPosition& c) { return HostGrids().m_occupancy[(size_t)c.row * m_columns + c.col] >= 0; }
+	int GetOccupancyValue(int row, int col) { return HostGrids().m_occupancy[(size_t)row * m_columns + col]; }
+	int GetOccupancyValue(const GridCellPosition& c) { return GetOccupancyValue(c.row, c.col); }
+	bool IsInsideMap(const GridCellPosition& c) const { return c.row >= 0 && c.row < m_rows && c.col >= 0 && c.col < m_columns; }
+	bool IsInsideMap(const Point2d& p) const { return IsInsideMap(WorldPositionToGridCell(p, false)); }
+	GridCellPosition LocalPositionToGridCell(const Point2d& p, bool bounded = true) const
+	{
+		// occupancy_map.h:106-117
+		int row = (int)((p.x() - m_localGridOrigin.x()) / resolution);
+		int col = (int)((p.y() - m_localGridOrigin.y()) / resolution);
+		if (!bounded || IsInsideMap(GridCellPosition(row, col)))
 			return { row, col };
 		return { -1, -1 };
 	}
+	GridCellPosition WorldPositionToGridCell(const Point2d& p, bool bounded = true) const
+	{
+		// occupancy_map.h:175-183
+		int row = (int)((p.x() - m_worldGridOrigin.x()) / resolution);
+		int col = (int)((p.y() - m_worldGridOrigin.y()) / resolution);
+		if (!bounded || IsInsideMap(GridCellPosition(row, col)))
+			return { row, col };
+		return { -1, -1 };
+	}
+	Point2d GridCellToLocalPosition(const GridCellPosition& c) const { return m_localGridOrigin + Point2d(c.row * resolution, c.col * resolution); }
 	Point2d GridCellToWorldPosition(const GridCellPosition& c) const { return m_worldGridOrigin + Point2d(c.row * resolution, c.col * resolution); }
+	Point2d LocalPositionToWorldPosition(const Point2d& p) const { return p + m_localOrigin; }
+	Point2d WorldPositionToLocalPosition(const Point2d& p) const { return p - m_localOrigin; } // occupancy_map.h:185-188
 	const Point2d& WorldGridOrigin() const { return m_worldGridOrigin; }
 	/// Squared obstacle distance (GVD::ObstacleDistanceMap::m_distance), occupancy ids and GVD::PathCostMap, row-major.
 	void SetGrids(const int32_t* occupancy, const int32_t* dist2, const float* pathCost)
 	{
+		HostGrids();
 		const size_t n = (size_t)m_rows * m_columns;
 		if (occupancy) m_occupancy.assign(occupancy, occupancy + n);
 		if (dist2) {
@@ -108,32 +142,145 @@ public:
 				m_distance[i] = DistanceOf(dist2[i]);
 		}
 		if (pathCost) m_pathCost.assign(pathCost, pathCost + n);
-		m_version++;
+		m_hostVersion++;
+		m_onDevice = false;
 	}
 	/// The distance grid as the reference's accessor returns it (float metres): ObstacleDistanceMap::GetDistanceToNearestObstacle
 	/// for every cell, row-major.  Use this when only the accessor is reachable (m_distance is private in the reference).
 	void SetDistances(const float* distance)
 	{
+		HostGrids();
 		m_distance.assign(distance, distance + (size_t)m_rows * m_columns);
-		m_version++;
+		m_hostVersion++;
+		m_onDevice = false;
 	}
 	/// gvd.h:38: `std::sqrt(m_distance[row][col]) * resolution` -- sqrt of the int in double, product in double, returned as float
 	float DistanceOf(int32_t d2) const { return (float)(std::sqrt((double)d2) * (double)resolution); }
-	float GetDistanceToNearestObstacle(int row, int col) const { return m_distance[(size_t)row * m_columns + col]; }
-	const std::vector<float>& Distance() const { return m_distance; }
-	Point2d WorldPositionToLocalPosition(const Point2d& p) const { return p - m_localOrigin; } // occupancy_map.h:185-188
-	const std::vector<int32_t>& Occupancy() const { return m_occupancy; }
-	const std::vector<int32_t>& Dist2() const { return m_dist2; }
-	const std::vector<float>& PathCost() const { return m_pathCost; }
-	uint64_t Version() const { return m_version; }
+	float GetDistanceToNearestObstacle(int row, int col) { return HostGrids().m_distance[(size_t)row * m_columns + col]; }
+	float GetPathCost(int row, int col) { return HostGrids().m_pathCost[(size_t)row * m_columns + col]; }
+	const std::vector<float>& Distance() { return HostGrids().m_distance; }
+	const std::vector<int32_t>& Occupancy() { return HostGrids().m_occupancy; }
+	const std::vector<int32_t>& Dist2() { return HostGrids().m_dist2; }
+	const std::vector<float>& PathCost() { return HostGrids().m_pathCost; }
+
+	/// StateSpaceSE2 bounds the validator checks poses against (state_validator_occupancy_map.cpp:18-20); without a validator
+	/// the map's own extent
+	void SetStateBounds(const std::array<Pose2d, 2>& b)
+	{
+		m_bounds = b;
+		m_hasBounds = true;
+		ResetDevice();
+	}
+	/// the device map set; host-side grids are pushed when they are the newer side
+	pp_map* Device()
+	{
+		if (m_rows <= 0)
+			throw std::runtime_error("The size of the occupancy matrix has not been initialized"); // obstacle_list_occupancy_map.cpp:31-32
+		if (!m_dev) {
+			pp_map_desc d {};
+			d.rows = m_rows;
+			d.cols = m_columns;
+			d.resolution = resolution;
+			d.grid_origin[0] = m_worldGridOrigin.x();
+			d.grid_origin[1] = m_worldGridOrigin.y();
+			d.local_origin[0] = m_localOrigin.x();
+			d.local_origin[1] = m_localOrigin.y();
+			if (m_hasBounds) {
+				d.lower[0] = m_bounds[0].x(), d.lower[1] = m_bounds[0].y(), d.lower[2] = m_bounds[0].theta;
+				d.upper[0] = m_bounds[1].x(), d.upper[1] = m_bounds[1].y(), d.upper[2] = m_bounds[1].theta;
+			} else {
+				d.lower[0] = m_localGridOrigin.x(), d.lower[1] = m_localGridOrigin.y(), d.lower[2] = -M_PI;
+				d.upper[0] = m_localGridOrigin.x() + m_width, d.upper[1] = m_localGridOrigin.y() + m_height, d.upper[2] = M_PI;
+			}
+			ppCheck(pp_map_create(HipContext::Get(), &d, &m_dev));
+			m_uploaded = ~0ull;
+			if (m_onDevice) { // the device grids went with the old handle: fall back to the host copies fetched before the reset
+				m_onDevice = false;
+				m_hostVersion++;
+			}
+		}
+		if (!m_onDevice && m_uploaded != m_hostVersion) {
+			ppCheck(pp_map_upload_distance(m_dev, m_distance.data()));
+			ppCheck(pp_map_upload_occupancy(m_dev, m_occupancy.data()));
+			ppCheck(pp_map_upload_path_cost(m_dev, m_pathCost.data()));
+			m_uploaded = m_hostVersion;
+		}
+		return m_dev;
+	}
+	/// GVD::Update (gvd.cpp:294-301) on the device, from the device occupancy grid
+	void BuildFields(float alpha, float dMax)
+	{
+		pp_map* d = Device(); // (pushes a host-set occupancy first)
+		ppCheck(pp_map_update_gvd(d, alpha, dMax, nullptr));
+		m_onDevice = true;
+		m_hostStale = true;
+		m_fieldsBuilt = true;
+	}
+	bool FieldsBuilt() const { return m_fieldsBuilt; }
+	/// obstacles were written on the device since the fields were last built (HybridAStar::SearchPath calls GVD::Update, hybrid_a_star.cpp:250)
+	bool FieldsOutdated() const { return m_onDevice && !m_fieldsBuilt; }
+	/// ObstacleListOccupancyMap: boundary cells get `value` on the device
+	void SetCellsOnDevice(const std::vector<GridCellPosition>& cells, int32_t value)
+	{
+		pp_map* d = Device();
+		static_assert(sizeof(GridCellPosition) == 8, "GridCellPosition is two ints");
+		ppCheck(pp_map_set_cells(d, (int64_t)cells.size(), cells.empty() ? nullptr : &cells[0].row, value));
+		m_onDevice = true;
+		m_hostStale = true;
+		m_fieldsBuilt = false;
+	}
+	/// Voronoi data of the last BuildFields (host copies), row-major
+	struct VoronoiGrids {
+		std::vector<int32_t> d2, nearestEdge, nearestObstacle;
+		std::vector<uint8_t> edge;
+	};
+	const VoronoiGrids& Voronoi()
+	{
+		HostGrids();
+		return m_voronoi;
+	}
 	const float resolution;
 
 protected:
+	/// host copies, fetched from the device when it holds the newer grids
+	OccupancyMap& HostGrids()
+	{
+		if (m_onDevice && m_hostStale && m_dev) {
+			const size_t n = (size_t)m_rows * m_columns;
+			ppCheck(pp_map_download_occupancy(m_dev, m_occupancy.data()));
+			if (m_fieldsBuilt) {
+				m_voronoi.d2.resize(n);
+				m_voronoi.edge.resize(n);
+				m_voronoi.nearestEdge.resize(2 * n);
+				m_voronoi.nearestObstacle.resize(2 * n);
+				ppCheck(pp_map_download_gvd(m_dev, m_dist2.data(), m_voronoi.nearestObstacle.data(), m_voronoi.edge.data(), m_voronoi.d2.data(), m_voronoi.nearestEdge.data(),
+					m_pathCost.data()));
+				for (size_t i = 0; i < n; i++)
+					m_distance[i] = DistanceOf(m_dist2[i]);
+			}
+			m_hostStale = false;
+		}
+		return *this;
+	}
+	void ResetDevice()
+	{
+		if (m_dev) {
+			HostGrids();
+			pp_map_destroy(m_dev);
+			m_dev = nullptr;
+		}
+	}
 	int m_rows = -1, m_columns = -1;
+	float m_width = 0, m_height = 0;
 	Point2d m_localOrigin, m_localGridOrigin, m_worldGridOrigin;
+	std::array<Pose2d, 2> m_bounds;
+	bool m_hasBounds = false;
 	std::vector<int32_t> m_occupancy, m_dist2;
 	std::vector<float> m_pathCost, m_distance;
-	uint64_t m_version = 0;
+	VoronoiGrids m_voronoi;
+	pp_map* m_dev = nullptr;
+	uint64_t m_hostVersion = 0, m_uploaded = ~0ull;
+	bool m_onDevice = false, m_hostStale = false, m_fieldsBuilt = false;
 };
 
 /// state_validator/state_validator.h:10-43 (SE2 instantiation)
@@ -180,11 +327,7 @@ public:
 		float width = stateSpace->bounds[1].x() - stateSpace->bounds[0].x();
 		float height = stateSpace->bounds[1].y() - stateSpace->bounds[0].y();
 		m_map->InitializeSize(width, height);
-	}
-	~StateValidatorOccupancyMap() override
-	{
-		if (m_dev)
-			pp_map_destroy(m_dev);
+		m_map->SetStateBounds(stateSpace->bounds);
 	}
 	bool IsStateValid(const Pose2d& state) override
 	{
@@ -274,32 +417,12 @@ public:
 		return out;
 	}
 	Ref<OccupancyMap>& GetOccupancyMap() { return m_map; }
-	/// device map set, (re)uploaded when the host grids or the tunables changed
+	/// the map's device map set with this validator's tunables pushed
 	pp_map* Device()
 	{
-		if (!m_dev) {
-			pp_map_desc d {};
-			d.rows = m_map->Rows();
-			d.cols = m_map->Columns();
-			d.resolution = m_map->resolution;
-			d.grid_origin[0] = m_map->WorldGridOrigin().x();
-			d.grid_origin[1] = m_map->WorldGridOrigin().y();
-			d.local_origin[0] = m_map->GetPosition().x();
-			d.local_origin[1] = m_map->GetPosition().y();
-			const auto& b = m_stateSpace->bounds;
-			d.lower[0] = b[0].x(); d.lower[1] = b[0].y(); d.lower[2] = b[0].theta;
-			d.upper[0] = b[1].x(); d.upper[1] = b[1].y(); d.upper[2] = b[1].theta;
-			ppCheck(pp_map_create(HipContext::Get(), &d, &m_dev));
-			m_uploaded = ~0ull;
-		}
-		if (m_uploaded != m_map->Version()) {
-			ppCheck(pp_map_upload_distance(m_dev, m_map->Distance().data()));
-			ppCheck(pp_map_upload_occupancy(m_dev, m_map->Occupancy().data()));
-			ppCheck(pp_map_upload_path_cost(m_dev, m_map->PathCost().data()));
-			m_uploaded = m_map->Version();
-		}
-		ppCheck(pp_map_set_validator(m_dev, minSafeRadius, minPathInterpolationDistance));
-		return m_dev;
+		pp_map* d = m_map->Device();
+		ppCheck(pp_map_set_validator(d, minSafeRadius, minPathInterpolationDistance));
+		return d;
 	}
 	float minPathInterpolationDistance = 0.1f; // state_validator_occupancy_map.h:27-28
 	float minSafeRadius = 1.0f;
@@ -343,8 +466,6 @@ private:
 		return true;
 	}
 	Ref<OccupancyMap> m_map;
-	pp_map* m_dev = nullptr;
-	uint64_t m_uploaded = ~0ull;
 };
 
 /// algo/hybrid_a_star.h:27-264 -- graph search on the GPU (post-processing / smoothing out of scope).
@@ -384,6 +505,8 @@ public:
 		if (!validator || !validator->GetStateSpace())
 			return isInitialized = false;
 		m_validator = validator;
+		if (validator->GetOccupancyMap()->FieldsOutdated())
+			validator->GetOccupancyMap()->BuildFields(20.0f, 30.0f); // the GVD the reference builds here (hybrid_a_star.cpp:212)
 		pp_hybrid_params hp { m_param.wheelbase, m_param.minTurningRadius, m_param.directionSwitchingCost, m_param.reverseCostMultiplier,
 			m_param.forwardCostMultiplier, m_param.voronoiCostMultiplier, m_param.numGeneratedMotion, m_param.spatialResolution, m_param.angularResolution, 1, 1 };
 		if (m_planner) {
@@ -400,6 +523,8 @@ public:
 	{
 		if (!isInitialized)
 			return Status::Failure; // "The algorithm has not been initialized successfully." (hybrid_a_star.cpp:243-246)
+		if (m_validator->GetOccupancyMap()->FieldsOutdated())
+			m_validator->GetOccupancyMap()->BuildFields(20.0f, 30.0f); // m_gvd->Update(), hybrid_a_star.cpp:250 (GVD::alpha / dMax, gvd.h:181)
 		m_validator->Device(); // pushes map edits / tunables
 		pp_query_result r {};
 		uint64_t seed = m_seed;
@@ -456,6 +581,8 @@ public:
 	{
 		if (!isInitialized || starts.size() != goals.size() || starts.size() != seeds.size())
 			throw std::invalid_argument("HybridAStar::SearchBatch: not initialised or size mismatch");
+		if (m_validator->GetOccupancyMap()->FieldsOutdated())
+			m_validator->GetOccupancyMap()->BuildFields(20.0f, 30.0f);
 		m_validator->Device();
 		std::vector<pp_query_result> res(starts.size());
 		if (!starts.empty())

@@ -13,6 +13,7 @@
 
 #include "planner_hip.hpp"
 #include "a_star.hpp"
+#include "map_authoring.hpp"
 
 namespace py = pybind11;
 using namespace Planner;
@@ -127,11 +128,23 @@ PYBIND11_MODULE(pyplanning, m)
 		.def("columns", &OccupancyMap::Columns)
 		.def("set_position", &OccupancyMap::SetPosition)
 		.def("get_position", &OccupancyMap::GetPosition)
+		.def("update", &OccupancyMap::Update)
 		.def("is_occupied", &OccupancyMap::IsOccupied)
-		.def("get_occupancy_value", &OccupancyMap::GetOccupancyValue)
+		.def("get_occupancy_value", py::overload_cast<int, int>(&OccupancyMap::GetOccupancyValue))
+		.def("get_occupancy_value", py::overload_cast<const GridCellPosition&>(&OccupancyMap::GetOccupancyValue))
+		.def("grid_cell_to_local_position", &OccupancyMap::GridCellToLocalPosition)
+		.def("local_position_to_grid_cell", &OccupancyMap::LocalPositionToGridCell, py::arg("position"), py::arg("bounded") = true)
+		.def("local_position_to_world_position", &OccupancyMap::LocalPositionToWorldPosition)
+		.def("world_position_to_local_position", &OccupancyMap::WorldPositionToLocalPosition)
+		.def("occupancy", [](OccupancyMap& map) {
+			py::array_t<int32_t> a({ map.Rows(), map.Columns() });
+			std::copy(map.Occupancy().begin(), map.Occupancy().end(), a.mutable_data());
+			return a;
+		})
 		.def("world_position_to_grid_cell", &OccupancyMap::WorldPositionToGridCell, py::arg("position"), py::arg("bounded") = true)
 		.def("grid_cell_to_world_position", &OccupancyMap::GridCellToWorldPosition)
-		.def("is_inside_map", &OccupancyMap::IsInsideMap)
+		.def("is_inside_map", py::overload_cast<const GridCellPosition&>(&OccupancyMap::IsInsideMap, py::const_))
+		.def("is_inside_map", py::overload_cast<const Point2d&>(&OccupancyMap::IsInsideMap, py::const_))
 		.def("set_grids",
 			[](OccupancyMap& map, py::array_t<int32_t, py::array::c_style | py::array::forcecast> occ, py::array_t<int32_t, py::array::c_style | py::array::forcecast> d2,
 				py::array_t<float, py::array::c_style | py::array::forcecast> pc) {
@@ -167,6 +180,42 @@ PYBIND11_MODULE(pyplanning, m)
 			})
 		.def_property("state_space", &StateValidatorSE2Base::GetStateSpace, nullptr);
 	py::class_<StateValidatorSE2Free, Ref<StateValidatorSE2Free>, StateValidatorSE2Base>(m, "StateValidatorSE2Free").def(py::init<const Ref<StateSpaceSE2>&>());
+
+	// ---- map authoring (pyplanning.cpp:364-400, 423-435) ----
+	py::class_<ObstacleListOccupancyMap, Ref<ObstacleListOccupancyMap>, OccupancyMap>(m, "ObstacleListOccupancyMap")
+		.def(py::init<float>())
+		.def("add_obstacle", &ObstacleListOccupancyMap::AddObstacle)
+		.def("remove_obstacle", &ObstacleListOccupancyMap::RemoveObstacle)
+		.def("get_num_obstacles", &ObstacleListOccupancyMap::GetNumObstacles);
+	py::class_<Obstacle, Ref<Obstacle>>(m, "Obstacle")
+		.def(py::init<>())
+		.def("set_shape", &Obstacle::SetShape)
+		.def("set_pose", &Obstacle::SetPose)
+		.def("get_boundary_grid_cell_position", &Obstacle::GetBoundaryGridCellPosition)
+		.def("get_boundary_world_position", &Obstacle::GetBoundaryWorldPosition);
+	struct ShapeWrapper : Shape {
+		using Shape::Shape;
+		void GetGridCellsPosition(OccupancyMap& a, const Pose2d& b, std::vector<GridCellPosition>& c) override { PYBIND11_OVERRIDE_PURE(void, Shape, GetGridCellsPosition, a, b, c); }
+		void GetVerticesPosition(const Pose2d& a, std::vector<Point2d>& b) override { PYBIND11_OVERRIDE_PURE(void, Shape, GetVerticesPosition, a, b); }
+	};
+	py::class_<Shape, Ref<Shape>, ShapeWrapper>(m, "Shape").def(py::init<>());
+	py::class_<CompositeShape, Ref<CompositeShape>, Shape>(m, "CompositeShape").def(py::init<>()).def("add", &CompositeShape::Add);
+	py::class_<PolygonShape, Ref<PolygonShape>, Shape>(m, "PolygonShape").def(py::init<const std::vector<Point2d>&>());
+	py::class_<RegularPolygonShape, Ref<RegularPolygonShape>, Shape>(m, "RegularPolygonShape").def(py::init<double, int>());
+	py::class_<RectangleShape, Ref<RectangleShape>, Shape>(m, "RectangleShape").def(py::init<double, double>());
+	py::class_<CircleShape, Ref<CircleShape>, Shape>(m, "CircleShape").def(py::init<double, int>());
+	py::class_<GVD>(m, "GVD")
+		.def(py::init<const Ref<OccupancyMap>&>())
+		.def("update", &GVD::Update)
+		.def("get_distance_to_nearest_obstacle", py::overload_cast<int, int>(&GVD::GetDistanceToNearestObstacle, py::const_))
+		.def("get_distance_to_nearest_obstacle", py::overload_cast<const GridCellPosition&>(&GVD::GetDistanceToNearestObstacle, py::const_))
+		.def("get_distance_to_nearest_voronoi_edge", py::overload_cast<int, int>(&GVD::GetDistanceToNearestVoronoiEdge, py::const_))
+		.def("get_distance_to_nearest_voronoi_edge", py::overload_cast<const GridCellPosition&>(&GVD::GetDistanceToNearestVoronoiEdge, py::const_))
+		.def("get_path_cost", py::overload_cast<int, int>(&GVD::GetPathCost, py::const_))
+		.def("get_path_cost", py::overload_cast<const GridCellPosition&>(&GVD::GetPathCost, py::const_))
+		.def("get_nearest_obstacle_cell", py::overload_cast<int, int>(&GVD::GetNearestObstacleCell, py::const_))
+		.def("get_nearest_voronoi_edge_cell", py::overload_cast<int, int>(&GVD::GetNearestVoronoiEdgeCell, py::const_))
+		.def("visualize", &GVD::Visualize);
 
 	py::class_<StateValidatorOccupancyMap, Ref<StateValidatorOccupancyMap>, StateValidatorSE2Base>(m, "StateValidatorOccupancyMap")
 		.def(py::init<const Ref<StateSpaceSE2>&, const Ref<OccupancyMap>&>())

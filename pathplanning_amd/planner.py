@@ -123,6 +123,49 @@ class OccupancyMapSet:
         assert dist.shape == (self.rows, self.cols)
         check(self.lib.pp_map_upload_distance(self.h, ptr(dist)))
 
+    # ---- map authoring / field construction on the device ----
+    def rasterize_segments(self, p0, p1, value):
+        """Shape::RasterizeLine for each world segment p0[i] -> p1[i]; writes `value` (obstacle id, or -1 to remove).  Returns cells written."""
+        a, b = _f64(p0, 2), _f64(p1, 2)
+        n = C.c_int32(0)
+        check(self.lib.pp_map_rasterize_segments(self.h, len(a), ptr(a), ptr(b), int(value), C.byref(n)))
+        return n.value
+
+    def add_polygon(self, vertices, pose, value):
+        """PolygonShape::GetGridCellsPosition (obstacle.cpp:77-93): vertices rotated / translated by `pose` on the host, edges
+        rasterised on the device."""
+        v = _f64(vertices, 2)
+        c, s_ = math.cos(pose[2]), math.sin(pose[2])
+        w = np.column_stack([c * v[:, 0] - s_ * v[:, 1] + pose[0], s_ * v[:, 0] + c * v[:, 1] + pose[1]])
+        return self.rasterize_segments(w, np.roll(w, -1, axis=0), value)
+
+    def download_occupancy(self):
+        occ = np.empty((self.rows, self.cols), dtype=np.int32)
+        check(self.lib.pp_map_download_occupancy(self.h, ptr(occ)))
+        return occ
+
+    def update_gvd(self, alpha=20.0, d_max=30.0):
+        """GVD::Update on the device from the device occupancy grid; returns the number of propagation steps."""
+        it = C.c_int32(0)
+        check(self.lib.pp_map_update_gvd(self.h, C.c_float(alpha), C.c_float(d_max), C.byref(it)))
+        return it.value
+
+    def download_gvd(self):
+        shape = (self.rows, self.cols)
+        out = dict(d2=np.empty(shape, np.int32), nearest_obstacle=np.empty(shape + (2,), np.int32), voronoi_edge=np.empty(shape, np.uint8),
+                   voronoi_d2=np.empty(shape, np.int32), nearest_edge=np.empty(shape + (2,), np.int32), path_cost=np.empty(shape, np.float32))
+        check(self.lib.pp_map_download_gvd(self.h, ptr(out["d2"]), ptr(out["nearest_obstacle"]), ptr(out["voronoi_edge"]), ptr(out["voronoi_d2"]),
+                                           ptr(out["nearest_edge"]), ptr(out["path_cost"])))
+        return out
+
+    def path_cost_update(self, obstacle_d2, voronoi_d2, alpha=20.0, d_max=30.0):
+        """PathCostMap::Update (gvd.cpp:266-283) over two squared-distance grids; becomes the map's path cost."""
+        a = np.ascontiguousarray(obstacle_d2, dtype=np.int32)
+        b = np.ascontiguousarray(voronoi_d2, dtype=np.int32)
+        out = np.empty((self.rows, self.cols), dtype=np.float32)
+        check(self.lib.pp_path_cost_update(self.h, ptr(a), ptr(b), C.c_float(alpha), C.c_float(d_max), ptr(out)))
+        return out
+
     def upload_occupancy(self, occ):
         occ = np.ascontiguousarray(occ, dtype=np.int32)
         assert occ.shape == (self.rows, self.cols)

@@ -1,0 +1,157 @@
+"""-m gpu: map authoring and field construction on the device against the oracle's restatement of
+state_validator/obstacle.cpp, obstacle_list_occupancy_map.cpp and gvd.cpp (the reference's dynamic brushfire with the same
+libstdc++ priority queue).  Exact: outline rasterisation, PathCostMap::Update.  Bounded: the two distance maps -- the device
+computes the fixed point of the brushfire's own 8-neighbour label propagation (= the exact EDT on these maps), the brushfire's
+heap order leaves a few tie cells short of it; Voronoi edges follow CheckVoro on final labels."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rect_vertices(dx, dy):
+    return [(dx / 2.0, dy / 2.0), (-dx / 2.0, dy / 2.0), (-dx / 2.0, -dy / 2.0), (dx / 2.0, -dy / 2.0)]  # RectangleShape, obstacle.cpp:106-110
+
+
+def circle_vertices(radius, count):
+    radius *= 1.0 / math.cos(math.pi / count)  # CircleShape, obstacle.cpp:112-122 (the angle goes through a float division)
+    return [(radius * math.cos(2 * math.pi * i / float(np.float32(count))), radius * math.sin(2 * math.pi * i / float(np.float32(count)))) for i in range(count)]
+
+
+def build_pair(n_cells, shapes, resolution=0.1):
+    """The same obstacles in the oracle world (AddObstacle) and on the device (host vertices, device Bresenham)."""
+    import pathplanning_amd as pa
+    half = n_cells * resolution / 2.0
+    w = O.World(half, half, resolution)
+    ctx = pa.Context(0)
+    ms = pa.OccupancyMapSet.from_bounds(ctx, w.lb, w.ub, resolution)
+    for k, (kind, a, b, pose) in enumerate(shapes):
+        if kind == "rect":
+            w.add_rectangle(a, b, pose)
+            ms.add_polygon(rect_vertices(a, b), pose, k)
+        else:
+            w.add_circle(a, b, pose)
+            ms.add_polygon(circle_vertices(a, b), pose, k)
+    return w, ms, ctx
+
+
+def seeded_shapes(n_cells, n, seed, resolution=0.1):
+    half = n_cells * resolution / 2.0
+    rng = np.random.RandomState(seed)
+    out = []
+    for k in range(n):
+        x, y = rng.uniform(-0.7 * half, 0.7 * half, 2)
+        th = rng.uniform(-math.pi, math.pi)
+        out.append(("rect", 0.3 * half, 0.04 * half, [x, y, th]) if k % 3 else ("circle", 0.08 * half, 10, [x, y, th]))
+    return out
+
+
+def test_outline_rasterisation_is_exact_and_removable():
+    w, ms, ctx = build_pair(256, seeded_shapes(256, 9, 5) + [("rect", 8.0, 1.0, [12.0, 12.0, 0.3])])  # the last one sticks out of the map
+    occ = ms.download_occupancy()
+    assert np.array_equal(occ, w.occ())
+    assert (occ >= 0).sum() > 500 and occ.max() == 9
+    # RemoveObstacle: the boundary cells go back to -1 (also where another outline crossed them, as in the reference)
+    ms.add_polygon(rect_vertices(8.0, 1.0), [12.0, 12.0, 0.3], -1)
+    assert (ms.download_occupancy() == 9).sum() == 0
+
+
+def test_path_cost_update_is_bit_exact():
+    import pathplanning_amd as pa
+    for cells, nobs, seed in ((256, 6, 3), (512, 12, 1)):
+        w = O.synthetic_world(cells, nobs, seed)
+        ctx = pa.Context(0)
+        ms = pa.OccupancyMapSet.from_bounds(ctx, w.lb, w.ub, 0.1)
+        got = ms.path_cost_update(w.d2(), w.voro_d2())
+        want = w.pathcost()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert (want > 0).mean() > 0.5
+
+
+def test_gvd_update_against_the_brushfire():
+    from scipy import ndimage
+    report = {}
+    for cells, n, seed in ((256, 6, 3), (512, 12, 1), (1024, 24, 1)):
+        w, ms, ctx = build_pair(cells, seeded_shapes(cells, n, seed))
+        w.update()
+        assert np.array_equal(ms.download_occupancy(), w.occ())
+        steps = ms.update_gvd()
+        g = ms.download_gvd()
+        d2, ref = g["d2"].astype(np.int64), w.d2().astype(np.int64)
+        edt = ndimage.distance_transform_edt(w.occ() < 0)
+        assert np.array_equal(d2, np.rint(edt * edt).astype(np.int64))  # the fixed point is the exact transform here
+        assert (d2 <= ref).all()  # the brushfire's values are distances to real obstacle cells: never below the minimum
+        diff = d2 != ref
+        assert diff.mean() < 2e-3 and (np.sqrt(ref) - np.sqrt(d2)).max() < 0.05  # a twentieth of a cell at most, on < 0.2 % of the cells
+        # the label is a nearest obstacle cell
+        lab = g["nearest_obstacle"]
+        rr, cc = np.meshgrid(np.arange(cells), np.arange(cells), indexing="ij")
+        assert np.array_equal((lab[..., 0] - rr) ** 2 + (lab[..., 1] - cc) ** 2, d2)
+        assert (w.occ()[lab[..., 0], lab[..., 1]] >= 0).all()
+        # Voronoi edges: CheckVoro on final labels vs the brushfire's incremental marks
+        edge, ref_edge = g["voronoi_edge"].astype(bool), w.voro_d2() == 0
+        both = (edge & ref_edge).sum()
+        iou = both / max(1, (edge | ref_edge).sum())
+        assert iou > 0.97, (cells, iou)
+        vd = np.sqrt(g["voronoi_d2"].astype(np.float64))
+        vr = np.sqrt(w.voro_d2().astype(np.float64))
+        assert np.abs(vd - vr).mean() < 0.1  # cells
+        # path cost: identical bits wherever both of its inputs agree with the brushfire's, close elsewhere
+        pc, ref_pc = g["path_cost"], w.pathcost()
+        same_in = (~diff) & (g["voronoi_d2"] == w.voro_d2())
+        assert np.array_equal(pc[same_in].view(np.uint32), ref_pc[same_in].view(np.uint32))
+        # a Voronoi mark that differs moves the potential of the cells around it (voroDist / (obstDist + voroDist) jumps at an
+        # edge cell): few cells, bounded on average
+        assert np.abs(pc - ref_pc).mean() < 2e-3 and (np.abs(pc - ref_pc) > 0.02).mean() < 0.02
+        report[str(cells)] = dict(propagation_steps=steps, d2_cells_differing=int(diff.sum()), d2_max_diff=int((ref - d2).max()), cells=cells * cells,
+                                  voronoi_edges_device=int(edge.sum()), voronoi_edges_brushfire=int(ref_edge.sum()), voronoi_edges_common=int(both),
+                                  voronoi_d2_equal_fraction=float((g["voronoi_d2"] == w.voro_d2()).mean()), path_cost_bits_equal_fraction=float((pc.view(np.uint32) == ref_pc.view(np.uint32)).mean()),
+                                  path_cost_max_abs_diff=float(np.abs(pc - ref_pc).max()), path_cost_mean_abs_diff=float(np.abs(pc - ref_pc).mean()))
+        # the validator reads the freshly built grids: same verdicts as the oracle wherever the distance cell agrees
+        import pathplanning_amd as pa
+        val = pa.StateValidatorOccupancyMap(ms)
+        rng = np.random.RandomState(1)
+        half = float(w.ub[0])
+        poses = np.column_stack([rng.uniform(-half, half, 20000), rng.uniform(-half, half, 20000), rng.uniform(-3.1, 3.1, 20000)])
+        cell = w.to_cell(poses[:, :2])
+        agree = ~diff[np.clip(cell[:, 0], 0, cells - 1), np.clip(cell[:, 1], 0, cells - 1)]
+        assert np.array_equal(val.is_state_valid(poses)[agree], w.is_state_valid(poses).astype(bool)[agree])
+    print("gvd parity:", json.dumps(report))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(report, open(os.path.join(ROOT, "gpurun_out", "gvd_parity.json"), "w"), indent=1)
+
+
+def test_planner_on_device_built_fields_matches_oracle_on_the_same_fields():
+    """End to end without any host-built grid: outlines -> device occupancy -> device GVD -> Hybrid A*.  The oracle searches on
+    the device's grids (downloaded), so the comparison is about the search, the field construction is compared above."""
+    import pathplanning_amd as pa
+    from gpu_common import valid_random_poses
+    w, ms, ctx = build_pair(256, seeded_shapes(256, 6, 11))
+    ms.update_gvd()
+    g = ms.download_gvd()
+    w.set_d2(g["d2"])
+    w.set_pathcost(g["path_cost"])
+    val = pa.StateValidatorOccupancyMap(ms)
+    rng = np.random.RandomState(2)
+    n = 12
+    starts, goals = valid_random_poses(rng, w, n), valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 5
+    planner = pa.HybridAStarBatch(val, pa.HybridAStarSearchParameters(), max_batch=n, max_nodes=32768)
+    planner.initialize()
+    res = planner.search_batch(starts, goals, seeds)
+    h = O.Hybrid(w, table=planner.nonholo_table())
+    ok = 0
+    for q in range(n):
+        r = h.search(starts[q], goals[q], int(seeds[q]))
+        assert res[q].status == r["status"] and np.array_equal(planner.get_expanded_of(q), r["expanded"])
+        if r["status"] == 0:
+            ok += 1
+            assert abs(res[q].cost - r["cost"]) < 1e-5
+    assert ok >= n // 2

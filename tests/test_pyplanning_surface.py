@@ -212,3 +212,109 @@ def test_generic_is_path_valid_and_graph_search_path_on_gpu(nav):
         assert abs(e.get_length() - r["path_length"][k + 1]) < 1e-6
         assert val.is_path_valid(e)
     assert isinstance(edges[-1], nav.PathReedsShepp) and isinstance(edges[0], nav.PathConstantSteer)
+
+
+def _example_obstacles(nav, scale=1.0):
+    """The four rectangles of interfaces/python/scripts/example.py:19-45 (poses as there)."""
+    out = []
+    for (dx, dy), pose in (((10.0, 1.0), (2.0, 0.0, -math.pi / 4.0)), ((10.0, 1.0), (0.0, 7.5, -math.pi / 4.0)), ((10.0, 1.0), (-8.0, 5.0, math.pi / 2.0)),
+                           ((14.0, 1.0), (5.0, -5.0, 0.0))):
+        o = nav.Obstacle()
+        o.set_shape(nav.RectangleShape(dx, dy))
+        o.set_pose(nav.Pose2d(*pose))
+        out.append((o, dx, dy, pose))
+    return out
+
+
+@pytest.mark.gpu
+def test_reference_example_script_flow_headless(nav, tmp_path):
+    """interfaces/python/scripts/example.py without the plotting: ObstacleListOccupancyMap + shapes + GVD + HybridAStar, every
+    grid built on the device.  Occupancy must equal the oracle's rasterisation; the search must equal the oracle's search on
+    the same (device-built) fields."""
+    import oracle_lib as O
+    state_space = nav.StateSpaceSE2(nav.Pose2d(-10, -10, -math.pi), nav.Pose2d(10, 10, math.pi))
+    m = nav.ObstacleListOccupancyMap(0.1)
+    validator = nav.StateValidatorOccupancyMap(state_space, m)
+    w = O.World(10.0, 10.0, 0.1)
+    positions = []
+    for o, dx, dy, pose in _example_obstacles(nav):
+        assert m.add_obstacle(o) and not m.add_obstacle(o)
+        w.add_rectangle(dx, dy, pose)
+        positions.append(o.get_boundary_world_position())
+        cells = o.get_boundary_grid_cell_position(m)
+        assert len(cells) > 100 and all(m.is_occupied(c) for c in cells[:5])
+    assert m.get_num_obstacles() == 4 and len(positions[0]) == 4
+    assert np.array_equal(m.occupancy(), w.occ())
+    gvd = nav.GVD(m)
+    gvd.update()
+    ppm = tmp_path / "test.ppm"
+    gvd.visualize(str(ppm))
+    assert ppm.stat().st_size > 200 * 200 * 3
+    w.update()
+    d = np.array([[gvd.get_distance_to_nearest_obstacle(r, c) for c in range(0, 200, 7)] for r in range(0, 200, 7)])
+    ref = (np.sqrt(w.d2()[::7, ::7].astype(np.float64)) * np.float64(np.float32(0.1))).astype(np.float32)
+    assert (d == ref).mean() > 0.995 and np.abs(d - ref).max() < 0.02
+    assert gvd.get_path_cost(100, 100) >= 0.0 and gvd.get_distance_to_nearest_voronoi_edge(nav.GridCellPosition(100, 100)) >= 0.0
+    algo = nav.HybridAStar()
+    algo.set_init_state(nav.Pose2d(0.0, -9.0, 0.0))
+    algo.set_goal_state(nav.Pose2d(8.0, 8.0, 0.0))
+    assert algo.initialize(validator)
+    algo.path_interpolation = 0.8
+    algo.set_seed(3)
+    assert algo.search_path() == nav.Status.SUCCESS
+    nodes = algo.get_path()
+    edges = algo.get_graph_search_path()
+    assert len(edges) == len(nodes) - 1 and abs(nodes[-1].x() - 8.0) < 1e-6
+    ratios = list(np.linspace(0.0, 1.0, 10))
+    for e in edges:
+        assert len(e.interpolate(ratios)) == 10
+    # the oracle on the device-built fields
+    d2 = np.rint((np.array([[m.get_distance_to_nearest_obstacle(r, c) for c in range(200)] for r in range(200)], dtype=np.float64) / np.float64(np.float32(0.1))) ** 2)
+    w.set_d2(d2.astype(np.int32))
+    w.set_pathcost(np.array([[gvd.get_path_cost(r, c) for c in range(200)] for r in range(200)], dtype=np.float32))
+    r = O.Hybrid(w).search([0.0, -9.0, 0.0], [8.0, 8.0, 0.0], 3)
+    assert r["status"] == 0 and len(r["path_poses"]) == len(nodes)
+    assert np.abs(np.array([[p.x(), p.y(), p.theta] for p in nodes]) - r["path_poses"]).max() < 1e-5
+    assert abs(algo.get_graph_search_optimal_cost() - r["cost"]) < 1e-5
+    # removing an obstacle frees its outline again; the fields are rebuilt at the next search
+    o0 = _example_obstacles(nav)[0][0]
+    assert not m.remove_obstacle(o0)  # a different object, not on the map
+
+
+@pytest.mark.gpu
+def test_reference_grid_example_script_flow_headless(nav):
+    """interfaces/python/scripts/example_a_star_grid.py without the plotting: obstacle outlines rasterised on the device, grid
+    A* and bidirectional A* on the host with Python callbacks."""
+    import oracle_lib as O
+    m = nav.ObstacleListOccupancyMap(0.5)
+    m.initialize_size(20, 20)
+    w = O.World(10.0, 10.0, 0.5)
+    for (dx, dy), pose in (((10.0, 1.0), (2.0, 0.0, -math.pi / 4.0)), ((10.0, 1.0), (0.0, 7.0, -math.pi / 4.0)), ((10.0, 1.0), (-8.0, 5.0, math.pi / 2.0)),
+                           ((14.0, 1.0), (5.0, -5.0, 0.0))):
+        o = nav.Obstacle()
+        o.set_shape(nav.RectangleShape(dx, dy))
+        o.set_pose(nav.Pose2d(*pose))
+        m.add_obstacle(o)
+        w.add_rectangle(dx, dy, pose)
+    assert (m.rows(), m.columns()) == (40, 40) and np.array_equal(m.occupancy(), w.occ())
+
+    def cost(a, b):
+        return math.sqrt((a.row - b.row) ** 2 + (a.col - b.col) ** 2)
+
+    prop, heur = nav.AStarStatePropagatorFcnN2(m, cost), nav.AStarHeuristicFcnN2(cost)
+    uni = nav.AStarN2()
+    uni.set_init_state(nav.GridCellPosition(1, 1))
+    uni.set_goal_state(nav.GridCellPosition(35, 35))
+    uni.initialize(prop, heur)
+    assert uni.search_path() == nav.Status.SUCCESS
+    want = O.grid_astar(w, (1, 1), (35, 35))
+    assert [(c.row, c.col) for c in uni.get_path()] == [tuple(c) for c in want["path"]] and uni.get_optimal_cost() == want["cost"]
+    hf, hr = nav.BidirectionalAStarN2.get_average_heuristic_pair(heur, heur)
+    bi = nav.BidirectionalAStarN2()
+    bi.set_init_state(nav.GridCellPosition(1, 1))
+    bi.set_goal_state(nav.GridCellPosition(35, 35))
+    bi.initialize(prop, prop, hf, hr)
+    assert bi.search_path() == nav.Status.SUCCESS
+    wb = O.grid_astar(w, (1, 1), (35, 35), bidirectional=True, inner_goal_f=(35, 35), inner_goal_r=(35, 35))
+    assert [(c.row, c.col) for c in bi.get_path()] == [tuple(c) for c in wb["path"]]
+    assert abs(bi.get_optimal_cost() - uni.get_optimal_cost()) < 1e-9
