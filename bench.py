@@ -288,7 +288,8 @@ def main():
             "config": {"workload": "Hybrid A* batch of %d start/goal pairs per GPU per step on one %dx%d map (res 0.1 m, %d rectangle outlines), P=%d constant-steer primitives + RS analytic expansion, exact-order obstacle heuristic per query" % (B, args.cells, args.cells, args.obstacles, planner.num_primitives),
                        "queries_per_gpu": B, "grid": [ms.rows, ms.cols], "parallelism": "query-sharded x%d" % n_gpus, "batches_in_flight": n_streams},
             "secondary": {"metric": "collision_checks_per_sec", "value": checks_per_s, "unit": "checks/s", "poses": n_chk, "ms": chk_ms,
-                          "achieved_GBs": chk_gbs, "hbm_frac": chk_gbs / HBM_PEAK_GBS,
+                          "achieved_GBs": chk_gbs, "hbm_frac": chk_gbs / HBM_PEAK_GBS, "bytes_per_pose_algorithmic": CHECK_BYTES_PER_POSE,
+                          "moved_GBs": n_chk * 25.0 / (chk_ms * 1e-3) / 1e9, "moved_frac": n_chk * 25.0 / (chk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "fused_checks_per_sec": n_chk / (fused_ms * 1e-3) * n_gpus,
                           "in_search_state_checks_per_sec": state_checks * n_gpus * args.steps / elapsed},
             "kernels_ms": {"k_wavefront": wf, search_kernel: se},

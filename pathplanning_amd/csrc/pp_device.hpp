@@ -174,6 +174,32 @@ PPD_INLINE bool is_state_valid_bit(const MapView& m, double x, double y, double 
 	return (m.validBits[cell >> 5] >> (cell & 31)) & 1u;
 }
 
+/// The same verdict without early exits (the streamed check kernel evaluates four poses per lane: eight nested exits and
+/// four inlined wrap loops cost more issue slots than the arithmetic).  Every condition is computed and and-ed; the heading is
+/// wrapped only when it lies outside [-pi, pi] (wrap_theta returns such values unchanged); the cell index is forced to 0 where
+/// the pose is outside the grid so that the bitmap load is always in range.  NaN coordinates: the reference's (int) conversion
+/// yields INT_MIN (outside), the device conversion yields 0 -- hence the explicit ordered tests.
+template <typename Bits>
+PPD_INLINE bool is_state_valid_bit_flat(const MapView& m, double x, double y, double theta, Bits validBits)
+{
+	const double lx = x - m.lox, ly = y - m.loy;
+	double lt = theta;
+	if (fabs(theta) > kPi)
+		lt = wrap_theta(theta);
+	const double qx = div_by(x - m.gx, (double)m.res, m.invRes), qy = div_by(y - m.gy, (double)m.res, m.invRes);
+	const bool inRange = qx > -2147483649.0 && qx < 2147483648.0 && qy > -2147483649.0 && qy < 2147483648.0; // false for NaN
+	const int row = (int)qx, col = (int)qy;
+	const bool bounds = !(lx < m.lbx) & !(lx > m.ubx) & !(ly < m.lby) & !(ly > m.uby) & !(lt < m.lbt) & !(lt > m.ubt);
+	const bool inside = inRange & ((unsigned)row < (unsigned)m.rows) & ((unsigned)col < (unsigned)m.cols);
+#ifdef PP_CS_EXPERIMENT_NO_GATHER // measurement only: every lookup hits word 0
+	const uint32_t cell = inside ? (uint32_t)(row & 1) : 0u;
+#else
+	const uint32_t cell = inside ? (uint32_t)row * (uint32_t)m.cols + (uint32_t)col : 0u;
+#endif
+	const uint32_t bit = (validBits[cell >> 5] >> (cell & 31)) & 1u; // the map's bitmap, or a copy of it in LDS
+	return bounds & inside & (bit != 0u);
+}
+
 /// KinematicBicycleModel::ConstantSteer with rearToCenter = 0 (beta = 0, cos(beta) = 1),
 /// models/kinematic_bicycle_model.cpp:5-32.  `kappa` = DthetaDdist (host libm),
 /// `dist` already carries the direction sign.  theta is not wrapped.

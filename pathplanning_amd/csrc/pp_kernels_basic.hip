@@ -7,6 +7,8 @@
 //   nonholo_build     a10 NonHolonomicHeuristic::Build
 //   knn               a14 exact k nearest neighbours (flann replacement)
 #include "pp_internal.hpp"
+
+#include <cstdlib>
 #include "pp_rs_device.hpp"
 
 using namespace ppd;
@@ -85,6 +87,101 @@ __global__ void __launch_bounds__(kBlock) k_check_states(MapView m, int64_t n, c
 			}
 		}
 		__syncthreads();
+	}
+}
+
+// The pipelined form for large aligned batches (16-byte aligned poses, 4-byte aligned flags; tails and unaligned views go
+// through the kernel above).  Same LDS staging -- a thread-per-group layout without it (each lane reading its own 96 bytes)
+// was measured at HALF the rate: a wave's 16-byte loads then spread over 48 cache lines instead of 8; staging per wave without
+// workgroup barriers measured 10 % slower -- with four changes: (0) a branch-free validity predicate (is_state_valid_bit_flat:
+// the early exits and wrap loops of four inlined checks were 36 exec-mask branches per tile);
+// (1) the NEXT tile's loads are issued into registers before the current tile is evaluated, so a workgroup always has 24 KiB
+// in flight instead of alternating between a load phase and a compute phase; (2) the pose stream is loaded non-temporally
+// (read once; the 128 KiB validity bitmap is what should stay cached); (3) the four flags of a thread's column go through LDS
+// and leave as ONE 32-bit word per thread: 256 contiguous bytes per wave store instead of 64.
+typedef double dvec2 __attribute__((ext_vector_type(2))); // (the non-temporal builtins take native vectors, not HIP's double2 struct)
+__global__ void __launch_bounds__(kBlock) k_check_states_pipe(MapView m, int64_t nTiles, const dvec2* __restrict__ src, uint32_t* __restrict__ valid4)
+{
+	constexpr int kTile = kBlock * kCsPer;          // poses per tile
+	constexpr int kVec = kCsPer * 3 / 2;            // 16-byte vectors per thread and tile
+	static_assert(kCsPer == 4, "four flags per 32-bit word");
+	__shared__ dvec2 tile[kTile * 3 / 2];
+	__shared__ uint8_t flags[2][kTile];
+	dvec2 v[kVec];
+	int64_t tileIdx = blockIdx.x;
+	if (tileIdx < nTiles) {
+		const dvec2* s2 = src + tileIdx * (kTile * 3 / 2);
+#pragma unroll
+		for (int k = 0; k < kVec; k++)
+			v[k] = __builtin_nontemporal_load(&s2[k * kBlock + threadIdx.x]);
+	}
+	int par = 0;
+	for (; tileIdx < nTiles; tileIdx += gridDim.x, par ^= 1) {
+#pragma unroll
+		for (int k = 0; k < kVec; k++)
+			tile[k * kBlock + threadIdx.x] = v[k];
+		__syncthreads();
+		const int64_t next = tileIdx + gridDim.x;
+		if (next < nTiles) { // in flight while this tile is evaluated
+			const dvec2* s2 = src + next * (kTile * 3 / 2);
+#pragma unroll
+			for (int k = 0; k < kVec; k++)
+				v[k] = __builtin_nontemporal_load(&s2[k * kBlock + threadIdx.x]);
+		}
+#pragma unroll
+		for (int k = 0; k < kCsPer; k++) {
+			const int i = k * kBlock + threadIdx.x;
+			const double* t = reinterpret_cast<const double*>(tile) + 3 * i;
+			flags[par][i] = is_state_valid_bit_flat(m, t[0], t[1], t[2], m.validBits) ? 1 : 0;
+		}
+		__syncthreads(); // flags complete; the tile may be overwritten by the next iteration
+		__builtin_nontemporal_store(reinterpret_cast<const uint32_t*>(flags[par])[threadIdx.x], &valid4[tileIdx * (kTile / 4) + threadIdx.x]);
+	}
+}
+
+// With the pose stream at the read-only rate, what is left is the bitmap look-up: 2^26 random 4-byte gathers through the
+// 32 KiB vector L1 are L2 round trips, 0.13 of the kernel's 0.42 ms (measured by pinning every look-up to word 0).  A bitmap of up
+// to 128 KiB (grids up to 1024 x 1024) fits in a CU's 160 KiB of LDS next to a 24 KiB pose tile: ONE workgroup of 1024 threads
+// per CU copies it in once and every look-up is a ds_read.  Two tiles of loads stay in flight in registers.
+constexpr int kLdsBlock = 1024;
+constexpr int kLdsTile = kLdsBlock; // one pose per thread and tile
+__global__ void __launch_bounds__(kLdsBlock) k_check_states_lds(MapView m, int64_t nTiles, const dvec2* __restrict__ src, uint32_t* __restrict__ valid4, int bitmapWords)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+	uint32_t* const bits = reinterpret_cast<uint32_t*>(lds);
+	dvec2* const tile = reinterpret_cast<dvec2*>(lds + (size_t)bitmapWords * 4);
+	uint8_t* const flags = reinterpret_cast<uint8_t*>(tile + kLdsTile * 3 / 2); // [2][kLdsTile]
+	const int tid = threadIdx.x;
+	for (int i = tid; i < bitmapWords / 4; i += kLdsBlock)
+		reinterpret_cast<uint4*>(bits)[i] = reinterpret_cast<const uint4*>(m.validBits)[i];
+	constexpr int kVecPerTile = kLdsTile * 3 / 2; // 1536 16-byte vectors: every thread loads one, the first half a second one
+	const bool second = tid < kVecPerTile - kLdsBlock;
+	dvec2 a0 = {}, b0 = {}, a1 = {}, b1 = {};
+	int64_t t0 = blockIdx.x, t1 = t0 + gridDim.x;
+	auto fetch = [&](int64_t tileIdx, dvec2& a, dvec2& b) {
+		if (tileIdx < nTiles) {
+			const dvec2* s2 = src + tileIdx * kVecPerTile;
+			a = __builtin_nontemporal_load(&s2[tid]);
+			if (second)
+				b = __builtin_nontemporal_load(&s2[kLdsBlock + tid]);
+		}
+	};
+	fetch(t0, a0, b0);
+	fetch(t1, a1, b1);
+	int par = 0;
+	for (int64_t tileIdx = blockIdx.x; tileIdx < nTiles; tileIdx += gridDim.x, par ^= 1) {
+		tile[tid] = a0;
+		if (second)
+			tile[kLdsBlock + tid] = b0;
+		__syncthreads(); // (the first pass also completes the bitmap copy)
+		a0 = a1;
+		b0 = b1;
+		fetch(tileIdx + 2 * (int64_t)gridDim.x, a1, b1); // two tiles ahead
+		const double* t = reinterpret_cast<const double*>(tile) + 3 * tid;
+		flags[par * kLdsTile + tid] = is_state_valid_bit_flat(m, t[0], t[1], t[2], bits) ? 1 : 0;
+		__syncthreads();
+		if (tid < kLdsTile / 4)
+			__builtin_nontemporal_store(reinterpret_cast<const uint32_t*>(flags + par * kLdsTile)[tid], &valid4[tileIdx * (kLdsTile / 4) + tid]);
 	}
 }
 
@@ -342,7 +439,40 @@ hipError_t launch_check_states(hipStream_t s, const MapView& m, int64_t n, const
 {
 	if (n <= 0)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_check_states, dim3(grid_for(n, kBlock * kCsPer, 256 * PP_CS_GRID_PER_CU)), dim3(kBlock), 0, s, m, n, poses, valid, (int)((((uintptr_t)poses) & 15) == 0));
+	static const bool staged = getenv("PP_CS_STAGED") && getenv("PP_CS_STAGED")[0] == '1'; // measurement switch: the round-1 kernel for everything
+	int64_t done = 0;
+	constexpr int kTile = kBlock * kCsPer;
+	const int64_t cells = (int64_t)m.rows * m.cols;
+	const int bitmapWords = (int)(((cells + 63) / 64) * 2);
+	static const int ldsMode = getenv("PP_CS_LDS") ? atoi(getenv("PP_CS_LDS")) : 1; // measurement switch: 0 = never use the LDS-resident bitmap
+	if (!staged && ldsMode && (((uintptr_t)poses) & 15) == 0 && (((uintptr_t)valid) & 3) == 0 && bitmapWords * 4 <= 128 * 1024 && bitmapWords % 4 == 0 && n >= (1 << 20)) {
+		const size_t ldsBytes = (size_t)bitmapWords * 4 + (size_t)kLdsTile * 24 + 2 * kLdsTile;
+		static bool attrSet = false;
+		if (!attrSet) { // more than 64 KiB of LDS per workgroup has to be asked for once
+			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_check_states_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			if (e != hipSuccess)
+				return e;
+			attrSet = true;
+		}
+		int dev = 0, cus = 256;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+			cus = prop.multiProcessorCount;
+		const int64_t tiles = n / kLdsTile;
+		hipLaunchKernelGGL(k_check_states_lds, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(kLdsBlock), ldsBytes, s, m, tiles, reinterpret_cast<const dvec2*>(poses),
+			reinterpret_cast<uint32_t*>(valid), bitmapWords);
+		done = tiles * kLdsTile;
+	} else if (!staged && (((uintptr_t)poses) & 15) == 0 && (((uintptr_t)valid) & 3) == 0 && n >= 64 * kTile) {
+		const int64_t tiles = n / kTile;
+		hipLaunchKernelGGL(k_check_states_pipe, dim3(grid_for(tiles, 1, 256 * PP_CS_GRID_PER_CU)), dim3(kBlock), 0, s, m, tiles, reinterpret_cast<const dvec2*>(poses),
+			reinterpret_cast<uint32_t*>(valid));
+		done = tiles * kTile;
+	}
+	if (done < n) { // the last partial tile, small batches, or views the pipelined form cannot take (done * 24 bytes keeps the 16-byte alignment)
+		const double* p = poses + 3 * done;
+		hipLaunchKernelGGL(k_check_states, dim3(grid_for(n - done, kBlock * kCsPer, 256 * PP_CS_GRID_PER_CU)), dim3(kBlock), 0, s, m, n - done, p, valid + done,
+			(int)((((uintptr_t)p) & 15) == 0));
+	}
 	return hipGetLastError();
 }
 hipError_t launch_valid_bits(hipStream_t s, const float* dist, int64_t cells, float minSafeRadius, uint32_t* bits)

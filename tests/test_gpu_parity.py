@@ -47,6 +47,28 @@ def test_check_states_bit_exact(env256):
     assert 0.05 < want.mean() < 0.95
 
 
+def test_check_states_large_batches_take_the_streaming_kernels(env256):
+    """Batches of >= 2^20 aligned poses run k_check_states_lds (validity bitmap copied into LDS, maps up to 1024^2), >= 2^16
+    k_check_states_pipe, the remainder the staged kernel: same verdicts, including a ragged tail and the edge cases in every part."""
+    import torch
+    w, ms, val, ctx = env256
+    rng = np.random.RandomState(5)
+    half = w.ub[0]
+    extra = np.array([[half, half, 0.0], [-half, -half, 0.0], [half + 1e-9, 0, 0], [0, -half - 1e-9, 0], [0, 0, math.pi], [0, 0, -math.pi], [0, 0, 3 * math.pi],
+                      [float("nan"), 0, 0], [0, float("nan"), 0], [0, 0, float("nan")], [1e300, 0, 0], [-1e300, 1e300, 0], [0, 0, 7.0], [0, 0, -7.0], [0, 0, 2.0e4],
+                      [half - 1e-12, half - 1e-12, 0]])
+    for n in ((1 << 20) + 1237, (1 << 16) + 77):
+        poses = random_poses(rng, w, n)
+        for at in (0, n // 2, n - len(extra)):
+            poses[at:at + len(extra)] = extra
+        want = w.is_state_valid(poses).astype(bool)
+        t = torch.from_numpy(poses).cuda()
+        out = val.is_state_valid(t)
+        ctx.synchronize()
+        assert np.array_equal(out.cpu().numpy().astype(bool), want)
+        assert 0.05 < want.mean() < 0.95
+
+
 def test_check_states_ragged_and_empty(env256):
     w, ms, val, ctx = env256
     rng = np.random.RandomState(1)
