@@ -75,7 +75,12 @@ def main():
     import pathplanning_amd as pa
     from pathplanning_amd import synthetic
 
-    m = synthetic.make_map(args.cells, args.obstacles, seed=1)
+    # the map set is made on rank 0 and broadcast (RCCL; 13 MB at 1024^2) -- what a deployment does with a map that exists on one
+    # rank only; the broadcast is outside the timed region, like the upload that follows it
+    from pathplanning_amd import sharding as _sh
+    m = synthetic.make_map(args.cells, args.obstacles, seed=1) if rank == 0 or world == 1 else None
+    if world > 1:
+        m = _sh.broadcast_map_set(m, 0, rank, world, device=dev)
     params = pa.HybridAStarSearchParameters()
     from pathplanning_amd import sharding
     B = args.batch if args.scaling == "weak" else len(sharding.shard_indices(args.batch, rank, max(world, 1)))

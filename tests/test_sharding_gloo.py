@@ -1,17 +1,20 @@
-"""N>1 path on CPU: two gloo ranks shard a query batch block-cyclically, plan their shards (CPU oracle
-stands in for the GPU planner here -- this test is about the sharding and the result gather), gather the
-fixed-size records, and must reproduce the single-process result query for query."""
+"""N > 1 path: two ranks shard a query batch block-cyclically, plan their shards, gather the fixed-size records (status, cost,
+counters AND the path poses) and must reproduce the single-process result query for query; the map set travels by
+broadcast from rank 0.  On CPU the ranks plan with the oracle (this part is about sharding, broadcast and gather, gloo); with a
+GPU present the same test body runs the real planner in both ranks on device 0 (-m gpu), the collectives still over gloo since
+RCCL refuses two ranks on one device."""
 import os
 import sys
 
 import numpy as np
-import torch
+import pytest
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+MAX_POSES = 96
 
 
 class _Rec:
@@ -19,15 +22,51 @@ class _Rec:
         self.status, self.cost, self.n_expanded, self.n_path = status, cost, n_expanded, n_path
 
 
-def _plan(indices, starts, goals, seeds):
+class OraclePlanner:
+    """the CPU oracle behind the two calls the sharded driver needs: search_batch + get_path_of"""
+
+    def __init__(self, m):
+        import oracle_lib as O
+        half = float(m["upper"][0])
+        self.w = O.World(half, half, m["resolution"])
+        self.w.set_occ(m["occ"])
+        self.w.set_d2(m["d2"])
+        self.w.set_pathcost(m["path_cost"])
+        self.h = O.Hybrid(self.w)
+        self.paths = []
+
+    def search_batch(self, starts, goals, seeds):
+        out, self.paths = [], []
+        for s, g, sd in zip(starts, goals, seeds):
+            r = self.h.search(s, g, int(sd))
+            out.append(_Rec(r["status"], r["cost"], len(r["expanded"]), len(r["path_poses"])))
+            self.paths.append(r["path_poses"])
+        return out
+
+    def get_path_of(self, q):
+        return dict(poses=self.paths[q])
+
+
+class GpuPlanner:
+    def __init__(self, m):
+        import pathplanning_amd as pa
+        from pathplanning_amd import synthetic
+        self.ctx = pa.Context(0)
+        self.ms, self.val = synthetic.upload(self.ctx, m)
+        self.pl = pa.HybridAStarBatch(self.val, pa.HybridAStarSearchParameters(), max_batch=16, max_nodes=32768)
+        self.pl.initialize()
+
+    def search_batch(self, starts, goals, seeds):
+        return self.pl.search_batch(starts, goals, np.asarray(seeds, dtype=np.uint64))
+
+    def get_path_of(self, q):
+        return self.pl.get_path_of(q)
+
+
+def _map():
     import oracle_lib as O
     w = O.synthetic_world(128, 3, 5)
-    h = O.Hybrid(w)
-    out = []
-    for i in indices:
-        r = h.search(starts[i], goals[i], int(seeds[i]))
-        out.append(_Rec(r["status"], r["cost"], len(r["expanded"]), len(r["path_poses"])))
-    return out
+    return dict(lower=w.lb.copy(), upper=w.ub.copy(), resolution=0.1, occ=w.occ(), d2=w.d2(), path_cost=w.pathcost())
 
 
 def _queries(n):
@@ -37,42 +76,66 @@ def _queries(n):
     return starts, goals, np.arange(n, dtype=np.uint64) + 50
 
 
-def _worker(rank, world, port, n, ret):
+def _plan(planner_cls, m, idx, starts, goals, seeds):
+    from pathplanning_amd import sharding
+    planner = planner_cls(m)
+    res = planner.search_batch(starts[idx], goals[idx], seeds[idx])
+    return sharding.records_from_results(res, len(idx), planner, MAX_POSES)
+
+
+def _worker(rank, world, port, n, backend, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pathplanning_amd import sharding
+    # only rank 0 has the map; the others receive it
+    m = sharding.broadcast_map_set(_map() if rank == 0 else None, 0, rank, world)
     starts, goals, seeds = _queries(n)
     idx = sharding.shard_indices(n, rank, world)
-    res = _plan(idx, starts, goals, seeds)
-    rec = sharding.records_from_results(res, len(idx))
+    rec = _plan(GpuPlanner if backend == "gpu" else OraclePlanner, m, idx, starts, goals, seeds)
     dist.barrier()
     full = sharding.gather_records(rec, n, rank, world)
     if rank == 0:
-        ret.put(full)
+        ret.put((full, {k: np.asarray(v) for k, v in m.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_sharding_matches_single_process():
+def _run_two_ranks(backend):
     from pathplanning_amd import sharding
     n = 7  # ragged: 4 + 3
     assert list(sharding.shard_indices(n, 0, 2)) == [0, 2, 4, 6]
     assert list(sharding.shard_indices(n, 1, 2)) == [1, 3, 5]
     starts, goals, seeds = _queries(n)
-    single = sharding.records_from_results(_plan(range(n), starts, goals, seeds), n)
+    m0 = _map()
+    single = _plan(OraclePlanner, m0, np.arange(n), starts, goals, seeds)  # the reference result: one process, CPU oracle
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, backend, ret)) for r in range(2)]
     for p in procs:
         p.start()
-    full = ret.get(timeout=300)
+    full, m_recv = ret.get(timeout=600)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    assert full.shape == single.shape
-    assert np.array_equal(np.isfinite(full), np.isfinite(single))
-    m = np.isfinite(single)
-    assert np.array_equal(full[m], single[m])
-    assert (single[:, 0] == 0).sum() >= 3
+    for k in ("occ", "d2", "path_cost", "lower", "upper"):
+        assert np.array_equal(m_recv[k], np.asarray(m0[k])), k
+    assert full.shape == single.shape == (n, sharding.record_width(MAX_POSES))
+    assert np.array_equal(full[:, [0, 2, 3]], single[:, [0, 2, 3]])  # status, expansions, path length: exact
+    ok = single[:, 0] == 0
+    assert ok.sum() >= 3
+    tol = 0.0 if backend == "oracle" else 1e-5
+    assert np.abs(full[ok][:, 1] - single[ok][:, 1]).max() <= tol
+    assert np.abs(full[ok][:, 4:] - single[ok][:, 4:]).max() <= tol
+    st, cost, nexp, poses = sharding.poses_of_record(full[np.argmax(ok)])
+    assert st == 0 and len(poses) >= 2 and np.abs(poses[0] - starts[np.argmax(ok)]).max() < 1e-9
+
+
+def test_two_rank_gloo_sharding_matches_single_process():
+    _run_two_ranks("oracle")
+
+
+@pytest.mark.gpu
+def test_two_ranks_plan_on_the_gpu_and_match_the_oracle():
+    _run_two_ranks("gpu")
