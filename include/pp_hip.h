@@ -267,6 +267,32 @@ int pp_planner_fetch_results(pp_planner* planner, int32_t n_queries, pp_query_re
 int pp_planner_get_path(pp_planner* planner, int32_t q, double* poses_host, int32_t* kind_host, int32_t* prim_host, double* length_host,
 	double* tuv_host);
 int pp_planner_get_expanded(pp_planner* planner, int32_t q, int32_t* cells_host);
+/* ---- after the graph search: HybridAStar::SearchPath's post-processing, batched -----------------
+ * (algo/hybrid_a_star.cpp:260-304: composite path of the solution's edges, sampling every path_interpolation metres with
+ * cusp snapping, then Smoother::Smooth, algo/smoother.cpp:33-226) for the first n_queries queries of the last batch, one
+ * workgroup per query.  Needs the nearest-obstacle / nearest-Voronoi-edge cell grids on the map (pp_map_update_gvd builds
+ * them, pp_map_upload_nearest_cells takes the reference's GVD::GetNearestObstacleCell / GetNearestVoronoiEdgeCell).
+ * smoother == NULL: Smoother::Parameters defaults with maxCurvature = 1 / minTurningRadius (hybrid_a_star.cpp:214). */
+typedef struct pp_smoother_params { /* algo/smoother.h:28-60 */
+	float step_tolerance;
+	int32_t max_iterations;
+	float learning_rate, path_weight, smooth_weight, voronoi_weight, collision_weight, curvature_weight, collision_ratio, max_curvature;
+} pp_smoother_params;
+typedef struct pp_post_result {
+	int32_t n_points;         /* poses of the sampled path (0: the search failed) */
+	int32_t smoothing_status; /* Smoother::Status: 0 MaxIteration, 1 StepTolerance, 2 PathSize, -1 Failure; -4: more than max_points samples */
+	int32_t iterations;
+	int32_t reserved;
+	double length;            /* length of the composite path */
+} pp_post_result;
+int pp_planner_postprocess(pp_planner* planner, int32_t n_queries, float path_interpolation, const pp_smoother_params* smoother, int32_t max_points,
+	pp_post_result* results_host);
+/* sampled path (3 doubles per pose), cusp flags, smoothed path of query q; any pointer may be NULL.  HybridAStar::GetPath() is the
+ * smoothed path when smoothing_status >= 0, else the sampled one (hybrid_a_star.cpp:293-303). */
+int pp_planner_get_processed_path(pp_planner* planner, int32_t q, double* sampled_host, uint8_t* cusp_host, double* smoothed_host);
+/* (row, col) per cell, row-major, (-1, -1) = none: the two label grids of the reference's GVD for maps whose fields were built elsewhere */
+int pp_map_upload_nearest_cells(pp_map* map, const int32_t* nearest_obstacle_host, const int32_t* nearest_edge_host);
+
 /* last batch: milliseconds spent in the wavefront kernel and in the search kernel (HIP events) */
 int pp_planner_last_timings(pp_planner* planner, float* wavefront_ms, float* search_ms);
 /* Diagnostics (never on by default): launch the stamped build of the search kernel and read, per query,

@@ -2,6 +2,7 @@
 // See ppo_geometry.hpp for the scope / parity-pinning statement.
 #include <cstring>
 #include "ppo_search.hpp"
+#include "ppo_post.hpp"
 
 #include <chrono>
 #include <thread>
@@ -383,6 +384,104 @@ void ppo_se2_paths_valid(void* wv, int64_t n, const double* from, const double* 
 		valid[i] = w->IsPathValid(p, &l) ? 1 : 0;
 		last[i] = l;
 	}
+}
+
+// --------------------------------------------- post-processing + smoother ----
+struct PostHandle {
+	std::vector<Pose2d> resampled, smoothed;
+	std::vector<uint8_t> cusp;
+	std::vector<double> ratios;
+	int status = -1, iterations = 0;
+	double length = 0.0;
+};
+/// hybrid_a_star.cpp:260-304 on a solution given as its nodes (root .. goal): hp = {wheelbase, minTurningRadius, reverseCostMultiplier,
+/// forwardCostMultiplier, directionSwitchingCost}; sp = {stepTolerance, maxIterations, learningRate, pathWeight, smoothWeight,
+/// voronoiWeight, collisionWeight, curvatureWeight, collisionRatio, maxCurvature}; nearestObstacle / nearestEdge: (row, col) per
+/// cell, or NULL for the world's own brushfire results.
+void* ppo_postprocess(void* wv, const double* hp, int nPath, const double* poses, const int* kind, const double* steering, const double* length, const int* direction,
+	const double* goal, float pathInterpolation, const float* sp, const int* nearestObstacle, const int* nearestEdge)
+{
+	World* w = (World*)wv;
+	auto* out = new PostHandle();
+	KinematicBicycleModel model;
+	model.wheelbase = hp[0];
+	PathComposite comp;
+	for (int i = 1; i < nPath; i++) {
+		Pose2d from = Pose2d::Raw(poses[3 * (i - 1)], poses[3 * (i - 1) + 1], poses[3 * (i - 1) + 2]);
+		if (kind[i] == 1) {
+			comp.PushBack(std::make_shared<PathConstantSteer>(&model, from, steering[i], length[i], (Direction)direction[i]));
+		} else {
+			auto seg = rs::GetOptimalPath(from, P3raw(goal), hp[1], (float)hp[2], (float)hp[3], (float)hp[4], nullptr, nullptr);
+			comp.PushBack(std::make_shared<PathReedsShepp>(from, seg, hp[1]));
+		}
+	}
+	out->length = comp.length;
+	std::unordered_set<int> cuspIndices;
+	if (!comp.parts.empty())
+		ResampleRatios(comp, pathInterpolation, out->ratios, cuspIndices);
+	for (double r : out->ratios)
+		out->resampled.push_back(comp.Interpolate(r));
+	out->cusp.assign(out->ratios.size(), 0);
+	for (int c : cuspIndices)
+		if (c >= 0 && c < (int)out->cusp.size())
+			out->cusp[c] = 1;
+	Grid<Cell> obs(w->rows, w->columns, Cell(-1, -1)), edg(w->rows, w->columns, Cell(-1, -1));
+	if (nearestObstacle && nearestEdge) {
+		for (int r = 0; r < w->rows; r++)
+			for (int c = 0; c < w->columns; c++) {
+				size_t i = ((size_t)r * w->columns + c) * 2;
+				obs.at(r, c) = Cell(nearestObstacle[i], nearestObstacle[i + 1]);
+				edg.at(r, c) = Cell(nearestEdge[i], nearestEdge[i + 1]);
+			}
+	}
+	Smoother sm;
+	sm.world = w;
+	sm.p.stepTolerance = sp[0];
+	sm.p.maxIterations = (int)sp[1];
+	sm.p.learningRate = sp[2];
+	sm.p.pathWeight = sp[3];
+	sm.p.smoothWeight = sp[4];
+	sm.p.voronoiWeight = sp[5];
+	sm.p.collisionWeight = sp[6];
+	sm.p.curvatureWeight = sp[7];
+	sm.p.collisionRatio = sp[8];
+	sm.p.maxCurvature = sp[9];
+	sm.nearestObstacle = nearestObstacle ? &obs : &w->obstacleMap->obstacle;
+	sm.nearestEdge = nearestEdge ? &edg : &w->voronoiMap->edge;
+	out->status = sm.Smooth(out->resampled, cuspIndices);
+	out->iterations = sm.iterations;
+	out->smoothed = sm.current;
+	return out;
+}
+void ppo_post_info(void* hv, int* nPoints, int* status, int* iterations, double* length)
+{
+	auto* h = (PostHandle*)hv;
+	*nPoints = (int)h->resampled.size();
+	*status = h->status;
+	*iterations = h->iterations;
+	*length = h->length;
+}
+void ppo_post_get(void* hv, double* resampled, uint8_t* cusp, double* smoothed, double* ratios)
+{
+	auto* h = (PostHandle*)hv;
+	for (size_t i = 0; i < h->resampled.size(); i++) {
+		resampled[3 * i] = h->resampled[i].x, resampled[3 * i + 1] = h->resampled[i].y, resampled[3 * i + 2] = h->resampled[i].theta;
+		cusp[i] = h->cusp[i];
+		ratios[i] = h->ratios[i];
+	}
+	for (size_t i = 0; i < h->smoothed.size(); i++)
+		smoothed[3 * i] = h->smoothed[i].x, smoothed[3 * i + 1] = h->smoothed[i].y, smoothed[3 * i + 2] = h->smoothed[i].theta;
+}
+void ppo_post_destroy(void* hv) { delete (PostHandle*)hv; }
+void ppo_world_get_nearest(void* wv, int* obstacle, int* edge)
+{
+	World* w = (World*)wv;
+	for (int r = 0; r < w->rows; r++)
+		for (int c = 0; c < w->columns; c++) {
+			size_t i = ((size_t)r * w->columns + c) * 2;
+			obstacle[i] = w->obstacleMap->obstacle.at(r, c).row, obstacle[i + 1] = w->obstacleMap->obstacle.at(r, c).col;
+			edge[i] = w->voronoiMap->edge.at(r, c).row, edge[i + 1] = w->voronoiMap->edge.at(r, c).col;
+		}
 }
 
 // ----------------------------------------------------------- heuristics ----

@@ -54,6 +54,16 @@ RS_PATH_DTYPE = np.dtype([("start", "<f8", 3), ("final_pose", "<f8", 3), ("motio
 assert RS_PATH_DTYPE.itemsize == 128
 
 
+class SmootherParams(C.Structure):
+    """Smoother::Parameters, algo/smoother.h:28-60"""
+    _fields_ = [("step_tolerance", C.c_float), ("max_iterations", C.c_int32), ("learning_rate", C.c_float), ("path_weight", C.c_float), ("smooth_weight", C.c_float),
+                ("voronoi_weight", C.c_float), ("collision_weight", C.c_float), ("curvature_weight", C.c_float), ("collision_ratio", C.c_float), ("max_curvature", C.c_float)]
+
+
+class PostResult(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("smoothing_status", C.c_int32), ("iterations", C.c_int32), ("reserved", C.c_int32), ("length", C.c_double)]
+
+
 class RrtResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_nodes", C.c_int32), ("n_path", C.c_int32), ("iterations", C.c_int64),
                 ("n_knn_queries", C.c_int64), ("n_edge_checks", C.c_int64)]
@@ -137,6 +147,9 @@ def load():
     L.pp_planner_fetch_results.argtypes = [vp, C.c_int32, vp]
     L.pp_planner_get_path.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
     L.pp_planner_get_expanded.argtypes = [vp, C.c_int32, vp]
+    L.pp_planner_postprocess.argtypes = [vp, C.c_int32, C.c_float, vp, C.c_int32, vp]
+    L.pp_planner_get_processed_path.argtypes = [vp, C.c_int32, vp, vp, vp]
+    L.pp_map_upload_nearest_cells.argtypes = [vp, vp, vp]
     L.pp_planner_last_timings.argtypes = [vp, c_fp, c_fp]
     L.pp_planner_set_profiling.argtypes = [vp, C.c_int32]
     L.pp_planner_phase_cycles.argtypes = [vp, C.c_int32, vp]

@@ -20,6 +20,7 @@
 #include "pp_internal.hpp"
 
 #include <climits>
+#include <vector>
 
 using namespace ppd;
 using pph::set_error;
@@ -514,6 +515,32 @@ int pp_map_download_gvd(pp_map* map, int32_t* d2_host, int32_t* nearest_obstacle
 	if (nearest_edge_host)
 		if (int rc = labels(map->voroLabel[map->voroResult], nearest_edge_host))
 			return rc;
+	return PP_OK;
+}
+
+int pp_map_upload_nearest_cells(pp_map* map, const int32_t* nearest_obstacle_host, const int32_t* nearest_edge_host)
+{
+	if (!map || !nearest_obstacle_host || !nearest_edge_host) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	if (map->desc.rows > 65535 || map->desc.cols > 65535) {
+		set_error("grids beyond 65535 cells a side are not supported by the label encoding");
+		return PP_ERR_CAPACITY;
+	}
+	PP_HIP_TRY(hipSetDevice(map->ctx->device));
+	const size_t n = map->cells();
+	PP_HIP_TRY(ensure((void**)&map->obstLabel[0], n * 4));
+	PP_HIP_TRY(ensure((void**)&map->voroLabel[0], n * 4));
+	std::vector<uint32_t> a(n), b(n);
+	for (size_t i = 0; i < n; i++) {
+		a[i] = nearest_obstacle_host[2 * i] < 0 ? kNone : ((uint32_t)nearest_obstacle_host[2 * i] << 16) | (uint32_t)nearest_obstacle_host[2 * i + 1];
+		b[i] = nearest_edge_host[2 * i] < 0 ? kNone : ((uint32_t)nearest_edge_host[2 * i] << 16) | (uint32_t)nearest_edge_host[2 * i + 1];
+	}
+	PP_HIP_TRY(hipMemcpy(map->obstLabel[0], a.data(), n * 4, hipMemcpyHostToDevice));
+	PP_HIP_TRY(hipMemcpy(map->voroLabel[0], b.data(), n * 4, hipMemcpyHostToDevice));
+	map->obstResult = 0;
+	map->voroResult = 0;
 	return PP_OK;
 }
 

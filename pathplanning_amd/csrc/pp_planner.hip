@@ -997,6 +997,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 }
 
 #include "pp_planner_rows.hpp"
+#include "pp_postprocess.hpp"
 
 } // namespace
 
@@ -1048,6 +1049,10 @@ struct pp_planner {
 	float wavefrontMs = 0, searchMs = 0;
 	int lastBatch = 0;
 	std::vector<DevResult> hostResults;
+	// post-processing (pp_postprocess.hpp), allocated at the first pp_planner_postprocess
+	PostBuffers post {};
+	int postMaxPoints = 0, postDone = 0;
+	std::vector<pp_post_result> hostPost;
 };
 
 namespace {
@@ -1057,7 +1062,7 @@ using pph::set_error;
 // Scratch the planner's kernels need per lane (largest private segment among them; tests/test_kernel_resources.py keeps
 // the figure honest against the built code object) and the number of hardware queues whose first dispatch may still have to
 // allocate it after this planner took its memory (bench.py runs with GPU_MAX_HW_QUEUES=16).
-constexpr size_t kMaxPrivateBytes = 512;
+constexpr size_t kMaxPrivateBytes = 1024;
 constexpr size_t kReserveQueues = 16;
 
 /// Empty dispatches of the three kernels a batch launches, on the planner's stream, then a synchronisation: the queue
@@ -1086,6 +1091,11 @@ int warm_up_kernels(pp_planner* p, pp_map* map)
 			(const SuspendRec*)nullptr, (const int*)nullptr, (const unsigned long long*)nullptr, (HeapEntry*)nullptr, 0.0, (uint8_t*)nullptr, (const int32_t*)nullptr, 0);
 		e = hipGetLastError();
 	}
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_postprocess, dim3(1), dim3(kPostThreads), 64, s, p->args, PostParams {}, 0, (const PathRec*)nullptr, (const RsLogEntry*)nullptr, (const DevResult*)nullptr,
+			(const uint32_t*)nullptr, (const uint32_t*)nullptr, PostBuffers {});
+		e = hipGetLastError();
+	}
 	if (e == hipSuccess)
 		e = hipStreamSynchronize(s);
 	(void)hipFree(ctl);
@@ -1112,6 +1122,10 @@ void free_planner(pp_planner* p)
 		}
 	}
 #endif
+	void* postPtrs[] = { p->post.ratios, p->post.resampled, p->post.smoothed, p->post.cusp, p->post.optimise, p->post.edgeEnd, p->post.out };
+	for (void* q : postPtrs)
+		if (q)
+			(void)hipFree(q);
 	void* ptrs[] = { p->bandMeta, p->bands, p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
@@ -1631,6 +1645,92 @@ int pp_planner_phase_cycles(pp_planner* planner, int32_t n_queries, uint64_t* cy
 	}
 	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
 	PP_HIP_TRY(hipMemcpy(cycles_host, planner->prof, (size_t)n_queries * PH_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	return PP_OK;
+}
+
+int pp_planner_postprocess(pp_planner* planner, int32_t n_queries, float path_interpolation, const pp_smoother_params* smoother, int32_t max_points, pp_post_result* results_host)
+{
+	if (!planner || n_queries < 0 || n_queries > planner->lastBatch || max_points < 8 || max_points > 8 * kPostThreads || !(path_interpolation > 0.0f)) {
+		set_error("invalid arguments (n_queries <= last batch, 8 <= max_points <= 2048, path_interpolation > 0)");
+		return PP_ERR_INVALID;
+	}
+	pp_map* map = planner->map;
+	if (!map->obstLabel[map->obstResult] || !map->voroLabel[map->voroResult]) {
+		set_error("nearest-obstacle / nearest-edge cell grids missing: pp_map_update_gvd or pp_map_upload_nearest_cells first");
+		return PP_ERR_INVALID;
+	}
+	if (n_queries == 0)
+		return PP_OK;
+	PP_HIP_TRY(hipSetDevice(map->ctx->device));
+	hipStream_t s = map->ctx->stream;
+	const size_t B = (size_t)planner->maxBatch;
+	if (planner->postMaxPoints < max_points) {
+		void* old[] = { planner->post.ratios, planner->post.resampled, planner->post.smoothed, planner->post.cusp, planner->post.optimise };
+		for (void* q : old)
+			if (q)
+				(void)hipFree(q);
+		planner->post.ratios = planner->post.resampled = planner->post.smoothed = nullptr;
+		planner->post.cusp = planner->post.optimise = nullptr;
+		PP_HIP_TRY(hipMalloc((void**)&planner->post.ratios, B * max_points * 8));
+		PP_HIP_TRY(hipMalloc((void**)&planner->post.resampled, B * max_points * 24));
+		PP_HIP_TRY(hipMalloc((void**)&planner->post.smoothed, B * max_points * 24));
+		PP_HIP_TRY(hipMalloc((void**)&planner->post.cusp, B * max_points));
+		PP_HIP_TRY(hipMalloc((void**)&planner->post.optimise, B * max_points));
+		planner->postMaxPoints = max_points;
+	}
+	if (!planner->post.edgeEnd)
+		PP_HIP_TRY(hipMalloc((void**)&planner->post.edgeEnd, B * (size_t)(planner->maxPath + 1) * 8));
+	if (!planner->post.out)
+		PP_HIP_TRY(hipMalloc((void**)&planner->post.out, B * sizeof(pp_post_result)));
+	PostParams P {};
+	P.pathInterpolation = path_interpolation;
+	pp_smoother_params sp { 1e-3f, 2000, 0.01f, 0.0f, 0.4f, 0.02f, 0.2f, 0.4f, 0.2f, (float)(1.0 / planner->params.min_turning_radius) }; // smoother.h:28-60, hybrid_a_star.cpp:214
+	if (smoother)
+		sp = *smoother;
+	P.stepTolerance = sp.step_tolerance;
+	P.maxIterations = sp.max_iterations;
+	P.learningRate = sp.learning_rate;
+	P.pathWeight = sp.path_weight;
+	P.smoothWeight = sp.smooth_weight;
+	P.voronoiWeight = sp.voronoi_weight;
+	P.collisionWeight = sp.collision_weight;
+	P.curvatureWeight = sp.curvature_weight;
+	P.collisionRatio = sp.collision_ratio;
+	P.maxCurvature = sp.max_curvature;
+	P.alpha = 20.0f; // GVD::alpha / dMax, gvd.h:181
+	P.dMax = 30.0f;
+	P.maxPoints = planner->postMaxPoints;
+	planner->args.m = map->view();
+	const size_t lds = (size_t)planner->postMaxPoints * 16;
+	hipLaunchKernelGGL(k_postprocess, dim3(n_queries), dim3(kPostThreads), lds, s, planner->args, P, n_queries, planner->paths, planner->rsLogs, planner->results,
+		map->obstLabel[map->obstResult], map->voroLabel[map->voroResult], planner->post);
+	PP_HIP_TRY(hipGetLastError());
+	planner->hostPost.resize(n_queries);
+	PP_HIP_TRY(hipMemcpyAsync(planner->hostPost.data(), planner->post.out, (size_t)n_queries * sizeof(pp_post_result), hipMemcpyDeviceToHost, s));
+	PP_HIP_TRY(hipStreamSynchronize(s));
+	planner->postDone = n_queries;
+	if (results_host)
+		for (int i = 0; i < n_queries; i++)
+			results_host[i] = planner->hostPost[i];
+	return PP_OK;
+}
+
+int pp_planner_get_processed_path(pp_planner* planner, int32_t q, double* sampled_host, uint8_t* cusp_host, double* smoothed_host)
+{
+	if (!planner || q < 0 || q >= planner->postDone) {
+		set_error("no post-processed result for this query (pp_planner_postprocess first)");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	const size_t n = (size_t)planner->hostPost[q].n_points, cap = (size_t)planner->postMaxPoints;
+	if (n == 0)
+		return PP_OK;
+	if (sampled_host)
+		PP_HIP_TRY(hipMemcpy(sampled_host, planner->post.resampled + (size_t)q * cap * 3, n * 24, hipMemcpyDeviceToHost));
+	if (cusp_host)
+		PP_HIP_TRY(hipMemcpy(cusp_host, planner->post.cusp + (size_t)q * cap, n, hipMemcpyDeviceToHost));
+	if (smoothed_host)
+		PP_HIP_TRY(hipMemcpy(smoothed_host, planner->post.smoothed + (size_t)q * cap * 3, n * 24, hipMemcpyDeviceToHost));
 	return PP_OK;
 }
 

@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import RS_PATH_DTYPE, HybridParams, MapDesc, QueryResult, check, ptr
+from ._lib import RS_PATH_DTYPE, HybridParams, MapDesc, PostResult, QueryResult, SmootherParams, check, ptr
 
 
 class Status:
@@ -165,6 +165,13 @@ class OccupancyMapSet:
         out = np.empty((self.rows, self.cols), dtype=np.float32)
         check(self.lib.pp_path_cost_update(self.h, ptr(a), ptr(b), C.c_float(alpha), C.c_float(d_max), ptr(out)))
         return out
+
+    def upload_nearest_cells(self, nearest_obstacle, nearest_edge):
+        """(rows, cols, 2) int grids: GVD::GetNearestObstacleCell / GetNearestVoronoiEdgeCell per cell (the smoother reads them)"""
+        a = np.ascontiguousarray(nearest_obstacle, dtype=np.int32)
+        b = np.ascontiguousarray(nearest_edge, dtype=np.int32)
+        assert a.shape == b.shape == (self.rows, self.cols, 2)
+        check(self.lib.pp_map_upload_nearest_cells(self.h, ptr(a), ptr(b)))
 
     def upload_occupancy(self, occ):
         occ = np.ascontiguousarray(occ, dtype=np.int32)
@@ -519,6 +526,35 @@ class HybridAStarBatch:
         if n:
             check(self.lib.pp_planner_get_path(self.h, q, ptr(poses), ptr(kind), ptr(prim), ptr(length), ptr(tuv)))
         return dict(poses=poses, kind=kind, prim=prim, length=length, tuv=tuv)
+
+    def postprocess(self, n_queries=None, path_interpolation=0.1, smoother=None, max_points=2048):
+        """HybridAStar::SearchPath's post-processing (hybrid_a_star.cpp:260-304) for the first n queries of the last batch: composite
+        path, sampling every `path_interpolation` metres with cusp snapping, Smoother::Smooth.  `smoother`: dict of
+        Smoother::Parameters fields to override (defaults: smoother.h:28-60, max_curvature = 1 / min_turning_radius).
+        Returns one PostResult per query (n_points, smoothing_status, iterations, length)."""
+        n = len(self._results) if n_queries is None else int(n_queries)
+        sp = None
+        if smoother is not None:
+            d = dict(step_tolerance=1e-3, max_iterations=2000, learning_rate=0.01, path_weight=0.0, smooth_weight=0.4, voronoi_weight=0.02, collision_weight=0.2,
+                     curvature_weight=0.4, collision_ratio=0.2, max_curvature=1.0 / self.params.min_turning_radius)
+            d.update(smoother)
+            sp = SmootherParams(**d)
+        out = (PostResult * max(n, 1))()
+        check(self.lib.pp_planner_postprocess(self.h, n, C.c_float(path_interpolation), C.byref(sp) if sp is not None else None, int(max_points), out))
+        self._post = list(out)[:n]
+        return self._post
+
+    def get_processed_path(self, q):
+        """sampled path, cusp flags and smoothed path of query q; `path` = what HybridAStar::GetPath() returns (the smoothed path
+        when smoothing succeeded, else the sampled one, hybrid_a_star.cpp:293-303)"""
+        r = self._post[q]
+        n = r.n_points
+        sampled, smoothed = np.empty((n, 3)), np.empty((n, 3))
+        cusp = np.empty(n, dtype=np.uint8)
+        if n:
+            check(self.lib.pp_planner_get_processed_path(self.h, q, ptr(sampled), ptr(cusp), ptr(smoothed)))
+        return dict(sampled=sampled, cusp=cusp.astype(bool), smoothed=smoothed, status=r.smoothing_status, iterations=r.iterations, length=r.length,
+                    path=smoothed if r.smoothing_status >= 0 else sampled)
 
     def get_expanded_of(self, q):
         r = self._results[q]

@@ -19,7 +19,7 @@ _u64p = C.POINTER(C.c_uint64)
 
 def _build():
     so = os.path.join(ORACLE_DIR, "libppo.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ppo_capi.cpp", "ppo_geometry.hpp", "ppo_world.hpp", "ppo_search.hpp")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("ppo_capi.cpp", "ppo_geometry.hpp", "ppo_world.hpp", "ppo_search.hpp", "ppo_post.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, os.path.join(ORACLE_DIR, "libppo.so")])
     return so
@@ -389,6 +389,54 @@ class Hybrid:
                     path_length=length, path_direction=direction, path_rsword=rsword, path_cost=pcost, n_nodes=int(info[3]),
                     n_state_checks=int(info[4]), n_path_checks=int(info[5]), n_rng_draws=int(info[6]), n_rs_attempts=int(info[7]),
                     n_children=int(info[8]))
+
+
+SMOOTHER_DEFAULTS = dict(step_tolerance=1e-3, max_iterations=2000, learning_rate=0.01, path_weight=0.0, smooth_weight=0.4, voronoi_weight=0.02,
+                         collision_weight=0.2, curvature_weight=0.4, collision_ratio=0.2, max_curvature=0.5)
+
+
+def smoother_array(**kw):
+    p = dict(SMOOTHER_DEFAULTS)
+    p.update(kw)
+    return np.array([p[k] for k in ("step_tolerance", "max_iterations", "learning_rate", "path_weight", "smooth_weight", "voronoi_weight", "collision_weight",
+                                    "curvature_weight", "collision_ratio", "max_curvature")], dtype=np.float32)
+
+
+def postprocess(world, result, goal, params=None, path_interpolation=0.1, smoother=None, nearest=None):
+    """hybrid_a_star.cpp:260-304 on a search result of Hybrid.search: resampled path, cusp flags, smoothing status, smoothed path.
+    nearest = (nearest_obstacle[rows, cols, 2], nearest_edge[rows, cols, 2]) to use label grids other than the world's brushfire."""
+    p = params_array() if params is None else params
+    hp = np.array([p[0], p[1], p[3], p[4], p[2]], dtype=np.float64)  # wheelbase, rmin, reverse, forward, switching
+    sp = smoother_array(max_curvature=1.0 / p[1]) if smoother is None else smoother
+    n = len(result["path_poses"])
+    poses = np.ascontiguousarray(result["path_poses"], dtype=np.float64)
+    kind = np.ascontiguousarray(result["path_kind"], dtype=np.int32)
+    steering = np.ascontiguousarray(result["path_steering"], dtype=np.float64)
+    length = np.ascontiguousarray(result["path_length"], dtype=np.float64)
+    direction = np.ascontiguousarray(result["path_direction"], dtype=np.int32)
+    no = ne = None
+    if nearest is not None:
+        no = np.ascontiguousarray(nearest[0], dtype=np.int32)
+        ne = np.ascontiguousarray(nearest[1], dtype=np.int32)
+    L = lib()
+    L.ppo_postprocess.restype = C.c_void_p
+    h = C.c_void_p(L.ppo_postprocess(world.h, dptr(hp), C.c_int(n), dptr(poses), iptr(kind), dptr(steering), dptr(length), iptr(direction), dptr(arr3(goal)),
+                                     C.c_float(path_interpolation), fptr(sp), iptr(no) if no is not None else None, iptr(ne) if ne is not None else None))
+    npts, status, iters, plen = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+    L.ppo_post_info(h, C.byref(npts), C.byref(status), C.byref(iters), C.byref(plen))
+    k = npts.value
+    resampled, smoothed, ratios = np.empty((k, 3)), np.empty((k, 3)), np.empty(k)
+    cusp = np.empty(k, dtype=np.uint8)
+    L.ppo_post_get(h, dptr(resampled), u8ptr(cusp), dptr(smoothed), dptr(ratios))
+    L.ppo_post_destroy(h)
+    return dict(n_points=k, status=status.value, iterations=iters.value, length=plen.value, resampled=resampled, cusp=cusp.astype(bool), smoothed=smoothed, ratios=ratios)
+
+
+def world_nearest(world):
+    no = np.empty((world.rows, world.cols, 2), dtype=np.int32)
+    ne = np.empty((world.rows, world.cols, 2), dtype=np.int32)
+    lib().ppo_world_get_nearest(world.h, iptr(no), iptr(ne))
+    return no, ne
 
 
 def hybrid_batch(world, table, starts, goals, seeds, threads=1, params=None, heading_alias=True, negative_k_read=True):

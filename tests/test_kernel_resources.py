@@ -48,5 +48,5 @@ def test_planner_headroom_covers_the_largest_private_segment():
     res = {k["kernel"]: k for k in kernel_resources.resources(lib)}
     src = open(os.path.join(ROOT, "pathplanning_amd", "csrc", "pp_planner.hip")).read()
     reserve = int(re.search(r"constexpr size_t kMaxPrivateBytes = (\d+);", src).group(1))
-    launched = [k for n, k in res.items() if n.startswith(("k_wavefront", "k_hybrid_search"))]
+    launched = [k for n, k in res.items() if n.startswith(("k_wavefront", "k_hybrid_search", "k_postprocess"))]
     assert launched and reserve >= max(k["scratch_bytes_per_lane"] for k in launched)
