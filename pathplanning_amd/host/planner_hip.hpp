@@ -154,6 +154,20 @@ public:
 		m_hostVersion++;
 		m_onDevice = false;
 	}
+	/// (row, col) per cell of GVD::GetNearestObstacleCell / GetNearestVoronoiEdgeCell, row-major: what the smoother reads
+	/// (algo/smoother.cpp:113,123) when the fields were built outside this library
+	void SetNearestCells(const int32_t* nearestObstacle, const int32_t* nearestEdge)
+	{
+		HostGrids();
+		const size_t n = (size_t)m_rows * m_columns * 2;
+		m_voronoi.nearestObstacle.assign(nearestObstacle, nearestObstacle + n);
+		m_voronoi.nearestEdge.assign(nearestEdge, nearestEdge + n);
+		m_nearestOnHost = true;
+		m_hostVersion++;
+		m_onDevice = false;
+	}
+	/// the post-processing of HybridAStar::SearchPath can run: the two label grids exist (built here or handed over)
+	bool HasNearestCells() const { return (m_onDevice && m_fieldsBuilt) || (!m_onDevice && m_nearestOnHost); }
 	/// gvd.h:38: `std::sqrt(m_distance[row][col]) * resolution` -- sqrt of the int in double, product in double, returned as float
 	float DistanceOf(int32_t d2) const { return (float)(std::sqrt((double)d2) * (double)resolution); }
 	float GetDistanceToNearestObstacle(int row, int col) { return HostGrids().m_distance[(size_t)row * m_columns + col]; }
@@ -203,6 +217,8 @@ public:
 			ppCheck(pp_map_upload_distance(m_dev, m_distance.data()));
 			ppCheck(pp_map_upload_occupancy(m_dev, m_occupancy.data()));
 			ppCheck(pp_map_upload_path_cost(m_dev, m_pathCost.data()));
+			if (m_nearestOnHost)
+				ppCheck(pp_map_upload_nearest_cells(m_dev, m_voronoi.nearestObstacle.data(), m_voronoi.nearestEdge.data()));
 			m_uploaded = m_hostVersion;
 		}
 		return m_dev;
@@ -257,6 +273,7 @@ protected:
 					m_pathCost.data()));
 				for (size_t i = 0; i < n; i++)
 					m_distance[i] = DistanceOf(m_dist2[i]);
+				m_nearestOnHost = true;
 			}
 			m_hostStale = false;
 		}
@@ -280,7 +297,7 @@ protected:
 	VoronoiGrids m_voronoi;
 	pp_map* m_dev = nullptr;
 	uint64_t m_hostVersion = 0, m_uploaded = ~0ull;
-	bool m_onDevice = false, m_hostStale = false, m_fieldsBuilt = false;
+	bool m_onDevice = false, m_hostStale = false, m_fieldsBuilt = false, m_nearestOnHost = false;
 };
 
 /// state_validator/state_validator.h:10-43 (SE2 instantiation)
@@ -468,7 +485,25 @@ private:
 	Ref<OccupancyMap> m_map;
 };
 
-/// algo/hybrid_a_star.h:27-264 -- graph search on the GPU (post-processing / smoothing out of scope).
+/// algo/smoother.h:18-60: the status codes and parameters of the path smoother (the descent itself runs in pp_planner_postprocess)
+struct Smoother {
+	enum Status { MaxIteration = 0, StepTolerance, PathSize, Failure = -1, Collision = -2 };
+	struct Parameters {
+		float stepTolerance = 1e-3;
+		int maxIterations = 2000;
+		float learningRate = 0.01f;
+		float pathWeight = 0.0f;
+		float smoothWeight = 0.4f;
+		float voronoiWeight = 0.02f;
+		float collisionWeight = 0.2f;
+		float curvatureWeight = 0.4f;
+		float collisionRatio = 0.2f;
+		float maxCurvature;
+		explicit Parameters(float maxCurvature) : maxCurvature(maxCurvature) { }
+	};
+};
+
+/// algo/hybrid_a_star.h:27-264 -- graph search and post-processing on the GPU.
 class HybridAStar : public PathPlannerSE2Base {
 public:
 	struct SearchParameters { // algo/hybrid_a_star.h:29-50
@@ -488,12 +523,14 @@ public:
 			forwardCostMultiplier(forwardCostMultiplier), voronoiCostMultiplier(voronoiCostMultiplier), numGeneratedMotion(numGeneratedMotion),
 			spatialResolution(spatialResolution), angularResolution(angularResolution) { }
 	};
-	struct Stats {
+	struct Stats { // algo/hybrid_a_star.h:52-55
 		Status graphSearchStatus = Status::Failure;
+		Smoother::Status smoothingStatus = Smoother::Status::Failure;
 	};
 
 	HybridAStar() : HybridAStar(SearchParameters()) { }
-	explicit HybridAStar(const SearchParameters& p, int maxBatch = 1, int maxNodes = 81920) : m_param(p), m_maxBatch(maxBatch), m_maxNodes(maxNodes) { }
+	explicit HybridAStar(const SearchParameters& p, int maxBatch = 1, int maxNodes = 81920) :
+		m_param(p), m_maxBatch(maxBatch), m_maxNodes(maxNodes), m_smootherParam((float)(1.0 / p.minTurningRadius)) { } // hybrid_a_star.cpp:214
 	~HybridAStar() override
 	{
 		if (m_planner)
@@ -531,10 +568,39 @@ public:
 		if (pp_planner_search_batch(m_planner, 1, &m_init.position.v[0], &m_goal.position.v[0], &seed, &r))
 			return m_stats.graphSearchStatus = Status::Failure;
 		m_last = r;
-		return m_stats.graphSearchStatus = (r.status == 0 ? Status::Success : Status::Failure);
+		m_path.clear();
+		m_smoothed.clear();
+		m_stats.smoothingStatus = Smoother::Status::Failure;
+		m_stats.graphSearchStatus = (r.status == 0 ? Status::Success : Status::Failure);
+		if (m_stats.graphSearchStatus < 0)
+			return m_stats.graphSearchStatus;
+		// hybrid_a_star.cpp:260-303: sample the composite path, smooth it; the smoothed path when that worked, else the sampled one.
+		// Needs the GVD's two nearest-cell grids (built by GVD::Update here, or handed over with OccupancyMap::SetNearestCells);
+		// a map that only carries the three grids of the search keeps the graph-search nodes as its path.
+		m_path = GetGraphSearchNodes();
+		if (m_validator->GetOccupancyMap()->HasNearestCells() && r.n_path >= 2) {
+			const pp_smoother_params sp { m_smootherParam.stepTolerance, m_smootherParam.maxIterations, m_smootherParam.learningRate, m_smootherParam.pathWeight,
+				m_smootherParam.smoothWeight, m_smootherParam.voronoiWeight, m_smootherParam.collisionWeight, m_smootherParam.curvatureWeight, m_smootherParam.collisionRatio,
+				m_smootherParam.maxCurvature };
+			pp_post_result post {};
+			if (pp_planner_postprocess(m_planner, 1, pathInterpolation, &sp, 2048, &post) == 0 && post.n_points > 0) {
+				std::vector<Pose2d> sampled((size_t)post.n_points), smoothed((size_t)post.n_points);
+				ppCheck(pp_planner_get_processed_path(m_planner, 0, &sampled[0].position.v[0], nullptr, &smoothed[0].position.v[0]));
+				m_stats.smoothingStatus = (Smoother::Status)post.smoothing_status;
+				m_smoothed = smoothed;
+				m_path = post.smoothing_status >= 0 ? smoothed : sampled;
+			}
+		}
+		return Status::Success;
 	}
-	/// graph-search path nodes (root .. goal)
-	std::vector<Pose2d> GetPath() const override
+	/// algo/hybrid_a_star.h:226: the sampled, and when the smoother succeeds smoothed, path (see SearchPath)
+	std::vector<Pose2d> GetPath() const override { return m_path; }
+	/// algo/hybrid_a_star.h:237: what the smoother ended with (also when it failed)
+	const std::vector<Pose2d>& GetSmoothedPath() const { return m_smoothed; }
+	const Smoother::Parameters& GetSmootherParameters() const { return m_smootherParam; }
+	void SetSmootherParameters(const Smoother::Parameters& p) { m_smootherParam = p; }
+	/// nodes of the graph-search solution, root .. goal (the end points of GetGraphSearchPath()'s edges)
+	std::vector<Pose2d> GetGraphSearchNodes() const
 	{
 		std::vector<Pose2d> out((size_t)m_last.n_path);
 		if (m_last.n_path > 0)
@@ -596,7 +662,7 @@ public:
 			ppCheck(pp_planner_get_path(m_planner, q, &out[0].position.v[0], nullptr, nullptr, nullptr, nullptr));
 		return out;
 	}
-	float pathInterpolation = 0.1f; // kept for source compatibility (post-processing is not in this library)
+	float pathInterpolation = 0.1f; // algo/hybrid_a_star.h:249: spacing of the sampled path
 
 private:
 	SearchParameters m_param;
@@ -605,6 +671,8 @@ private:
 	Ref<StateValidatorOccupancyMap> m_validator;
 	pp_planner* m_planner = nullptr;
 	pp_query_result m_last {};
+	Smoother::Parameters m_smootherParam;
+	std::vector<Pose2d> m_path, m_smoothed;
 	Stats m_stats;
 	uint64_t m_seed = 0;
 };

@@ -161,7 +161,15 @@ PYBIND11_MODULE(pyplanning, m)
 				map.SetDistances(d.data());
 			},
 			py::arg("distance"))
-		.def("get_distance_to_nearest_obstacle", &OccupancyMap::GetDistanceToNearestObstacle);
+		.def("get_distance_to_nearest_obstacle", &OccupancyMap::GetDistanceToNearestObstacle)
+		.def("set_nearest_cells",
+			[](OccupancyMap& map, py::array_t<int32_t, py::array::c_style | py::array::forcecast> o, py::array_t<int32_t, py::array::c_style | py::array::forcecast> e) {
+				const size_t n = (size_t)map.Rows() * map.Columns() * 2;
+				if ((size_t)o.size() != n || (size_t)e.size() != n)
+					throw std::invalid_argument("set_nearest_cells: arrays must be rows x columns x 2");
+				map.SetNearestCells(o.data(), e.data());
+			},
+			py::arg("nearest_obstacle"), py::arg("nearest_edge"));
 
 	struct StateValidatorSE2BaseWrapper : StateValidatorSE2Base { // pyplanning.cpp:402-406 (whose IsPathValid trampoline dispatches to IsStateValid, Q18)
 		using StateValidatorSE2Base::StateValidatorSE2Base;
@@ -264,7 +272,27 @@ PYBIND11_MODULE(pyplanning, m)
 		.def_readonly("spatial_resolution", &HybridAStar::SearchParameters::spatialResolution)
 		.def_readonly("angular_resolution", &HybridAStar::SearchParameters::angularResolution);
 
-	py::class_<HybridAStar::Stats>(m, "HybridAStarStats").def_readonly("graph_search_status", &HybridAStar::Stats::graphSearchStatus);
+	py::class_<Smoother::Parameters>(m, "HybridAStarSmootherParameters") // pyplanning.cpp:86-97
+		.def(py::init<float>())
+		.def_readwrite("step_tolerance", &Smoother::Parameters::stepTolerance)
+		.def_readwrite("max_iterations", &Smoother::Parameters::maxIterations)
+		.def_readwrite("learning_rate", &Smoother::Parameters::learningRate)
+		.def_readwrite("path_weight", &Smoother::Parameters::pathWeight)
+		.def_readwrite("smooth_weight", &Smoother::Parameters::smoothWeight)
+		.def_readwrite("voronoi_weight", &Smoother::Parameters::voronoiWeight)
+		.def_readwrite("collision_weight", &Smoother::Parameters::collisionWeight)
+		.def_readwrite("curvature_weight", &Smoother::Parameters::curvatureWeight)
+		.def_readwrite("collision_ratio", &Smoother::Parameters::collisionRatio)
+		.def_readonly("max_curvature", &Smoother::Parameters::maxCurvature);
+	py::enum_<Smoother::Status>(m, "SmoothingStatus") // pyplanning.cpp:103-108
+		.value("MAX_ITERATION", Smoother::Status::MaxIteration)
+		.value("STEP_TOLERANCE", Smoother::Status::StepTolerance)
+		.value("PATH_SIZE", Smoother::Status::PathSize)
+		.value("FAILURE", Smoother::Status::Failure)
+		.value("COLLISION", Smoother::Status::Collision);
+	py::class_<HybridAStar::Stats>(m, "HybridAStarStats")
+		.def_readonly("graph_search_status", &HybridAStar::Stats::graphSearchStatus)
+		.def_readonly("smoothing_status", &HybridAStar::Stats::smoothingStatus);
 
 	py::class_<HybridAStar, PathPlannerSE2Base>(m, "HybridAStar")
 		.def(py::init<>())
@@ -275,6 +303,9 @@ PYBIND11_MODULE(pyplanning, m)
 		.def("get_stats", &HybridAStar::GetStats)
 		.def("get_graph_search_optimal_cost", &HybridAStar::GetGraphSearchOptimalCost)
 		.def("get_graph_search_path", &HybridAStar::GetGraphSearchPath)
+		.def("get_graph_search_nodes", &HybridAStar::GetGraphSearchNodes)
+		.def("get_smoothed_path", &HybridAStar::GetSmoothedPath)
+		.def_property("smoother_parameters", &HybridAStar::GetSmootherParameters, &HybridAStar::SetSmootherParameters)
 		.def("get_search_parameters", &HybridAStar::GetSearchParameters)
 		.def("set_seed", &HybridAStar::SetSeed)
 		.def("search_batch",

@@ -262,12 +262,21 @@ def test_reference_example_script_flow_headless(nav, tmp_path):
     algo.path_interpolation = 0.8
     algo.set_seed(3)
     assert algo.search_path() == nav.Status.SUCCESS
-    nodes = algo.get_path()
+    nodes = algo.get_graph_search_nodes()
     edges = algo.get_graph_search_path()
     assert len(edges) == len(nodes) - 1 and abs(nodes[-1].x() - 8.0) < 1e-6
     ratios = list(np.linspace(0.0, 1.0, 10))
     for e in edges:
         assert len(e.interpolate(ratios)) == 10
+    # GetPath(): the composite path sampled every 0.8 m, smoothed when the smoother succeeds (hybrid_a_star.cpp:260-303)
+    path = algo.get_path()
+    stats = algo.get_stats()
+    assert stats.graph_search_status == nav.Status.SUCCESS
+    assert len(path) > len(nodes) or algo.path_interpolation > 1.4
+    # (the last sample is the goal only when the path length falls within half a step of a multiple of the step, hybrid_a_star.cpp:276-287)
+    assert abs(path[0].x() - 0.0) < 1e-9 and abs(path[0].y() + 9.0) < 1e-9 and math.hypot(path[-1].x() - 8.0, path[-1].y() - 8.0) < 0.8 + 1e-9
+    assert len(algo.get_smoothed_path()) == len(path)
+    assert algo.smoother_parameters.max_curvature == np.float32(0.5) and algo.smoother_parameters.max_iterations == 2000
     # the oracle on the device-built fields
     d2 = np.rint((np.array([[m.get_distance_to_nearest_obstacle(r, c) for c in range(200)] for r in range(200)], dtype=np.float64) / np.float64(np.float32(0.1))) ** 2)
     w.set_d2(d2.astype(np.int32))
@@ -276,6 +285,13 @@ def test_reference_example_script_flow_headless(nav, tmp_path):
     assert r["status"] == 0 and len(r["path_poses"]) == len(nodes)
     assert np.abs(np.array([[p.x(), p.y(), p.theta] for p in nodes]) - r["path_poses"]).max() < 1e-5
     assert abs(algo.get_graph_search_optimal_cost() - r["cost"]) < 1e-5
+    # ... and the oracle's post-processing on the device's label grids
+    no = np.array([[[c.row, c.col] for c in (gvd.get_nearest_obstacle_cell(r_, c_) for c_ in range(200))] for r_ in range(200)], dtype=np.int32)
+    ne = np.array([[[c.row, c.col] for c in (gvd.get_nearest_voronoi_edge_cell(r_, c_) for c_ in range(200))] for r_ in range(200)], dtype=np.int32)
+    want = O.postprocess(w, r, [8.0, 8.0, 0.0], path_interpolation=0.8, nearest=(no, ne))
+    assert want["n_points"] == len(path) and int(stats.smoothing_status) == want["status"]
+    got = np.array([[p.x(), p.y(), p.theta] for p in path])
+    assert np.abs(got - (want["smoothed"] if want["status"] >= 0 else want["resampled"])).max() < 1e-5
     # removing an obstacle frees its outline again; the fields are rebuilt at the next search
     o0 = _example_obstacles(nav)[0][0]
     assert not m.remove_obstacle(o0)  # a different object, not on the map
