@@ -309,8 +309,12 @@ int pp_knn(pp_ctx* ctx, int64_t n_points, const double* points_host, int64_t n_q
 	int32_t* idx_host, double* d2_host);
 
 /* ---- a13: RRT / RRT* (algo/rrt.h:55-95, algo/rrt_star.h:53-112) ------------
- * Host loop owning the RNG + device kNN / edge checks.  map == NULL: free space
- * (StateValidatorFree).  params = {maxIteration, maxNumberTreeNode, maxConnectionDistance, goalBias}. */
+ * The whole loop runs on the device, one workgroup per tree.  map == NULL: free space
+ * (StateValidatorFree).  params = {maxIteration, maxNumberTreeNode, maxConnectionDistance, goalBias[, gamma]}.
+ * star: 0 = RRT, 1 = RRT* exactly as the reference (choose-parent among the k = ln N nearest, NO rewire: rrt_star.h:83-97);
+ * beyond the reference: 2 = + rewire of the near nodes through the new node with the saving carried down
+ * their subtrees (what utils/node.h:203-225 Reparent is for), 3 = the same with a radius near-set, the <= 16 nearest nodes
+ * within params[4] * sqrt(ln(n + 1) / (n + 1)). */
 typedef struct pp_rrt_result {
 	int32_t status;
 	int32_t n_nodes;

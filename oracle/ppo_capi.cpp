@@ -885,7 +885,9 @@ void* ppo_rrt(void* wv, const double* lb, const double* ub, const double* params
 	p.maxNumberTreeNode = (unsigned int)params[1];
 	p.maxConnectionDistance = params[2];
 	p.goalBias = params[3];
-	auto* res = new RRTResult(star ? RRTStar(prob, p, { init[0], init[1] }, { goal[0], goal[1] }, seed) : RRT(prob, p, { init[0], init[1] }, { goal[0], goal[1] }, seed));
+	// star: 0 RRT, 1 RRT* (reference), 2 / 3 the rewire extensions (gamma = params[4] for 3)
+	auto* res = new RRTResult(star ? RRTStar(prob, p, { init[0], init[1] }, { goal[0], goal[1] }, seed, star, star == 3 ? params[4] : 0.0)
+	                               : RRT(prob, p, { init[0], init[1] }, { goal[0], goal[1] }, seed));
 	return res;
 }
 /// info = {status, nNodes, nPath, iterations, nKnnQueries, nEdgeChecks}

@@ -1074,9 +1074,19 @@ inline RRTResult RRT(const R2Problem& prob, const RRTParams& p, const Point2d& i
 	return res;
 }
 
-/// rrt_star.h:53-112 -- choose-parent only, no rewire (Q15).
-inline RRTResult RRTStar(const R2Problem& prob, const RRTParams& p, const Point2d& init, const Point2d& goal, uint64_t seed)
+/// rrt_star.h:53-112 -- choose-parent only, no rewire (Q15): mode 1.
+/// Modes 2 / 3 are NOT in the reference (its FIXME at rrt_star.h:83): the definition the product's extension is tested against --
+/// after the new node is linked, every near node (in near-set order) that gets cheaper through it and whose connecting edge
+/// is valid is re-parented to it (Node::Reparent, utils/node.h:203-225) and its subtree's costs follow (cost = parent cost +
+/// stored edge length); mode 3 takes as near-set the <= 16 nearest nodes within gamma * sqrt(ln(n + 1) / (n + 1)).
+inline RRTResult RRTStar(const R2Problem& prob, const RRTParams& p, const Point2d& init, const Point2d& goal, uint64_t seed, int mode = 1, double gamma = 0.0)
 {
+	std::vector<std::vector<int>> children; // modes 2 / 3
+	std::vector<double> edgeLen;
+	if (mode >= 2) {
+		children.emplace_back();
+		edgeLen.push_back(0.0);
+	}
 	RRTResult res;
 	Rng rng(seed);
 	PointTree tree;
@@ -1097,7 +1107,21 @@ inline RRTResult RRTStar(const R2Problem& prob, const RRTParams& p, const Point2
 			continue;
 		Point2d newState = pathNearToNew.final;
 		unsigned int nn = std::max<unsigned int>(1, std::log(tree.Size())); // rrt_star.h:84
+		if (mode == 3)
+			nn = (unsigned int)std::min<size_t>(16, tree.Size());
 		std::vector<int> nearNodes = tree.Nearest(newState, nn);
+		if (mode == 3) {
+			const double np1 = (double)tree.Size() + 1.0;
+			const double radius = gamma * std::sqrt(std::log(np1) / np1);
+			size_t m = 0;
+			while (m < nearNodes.size()) {
+				double dx = tree.pts[nearNodes[m]].x - newState.x, dy = tree.pts[nearNodes[m]].y - newState.y;
+				if (!(dx * dx + dy * dy <= radius * radius))
+					break;
+				m++;
+			}
+			nearNodes.resize(std::max<size_t>(1, m));
+		}
 		int bestParent = -1;
 		double bestCost = std::numeric_limits<double>::infinity();
 		for (int node : nearNodes) {
@@ -1114,8 +1138,40 @@ inline RRTResult RRTStar(const R2Problem& prob, const RRTParams& p, const Point2
 		int src = bestParent;
 		if (src < 0 && tree.index.find({ newState.x, newState.y }) == tree.index.end())
 			src = tree.Nearest(newState, 1)[0];
+		const size_t sizeBefore = tree.pts.size();
 		int newNode = tree.Extend(newState, src);
 		tree.cost[newNode] = bestCost; // rrt_star.h:101 (also overwrites an existing node's cost)
+		if (mode >= 2 && tree.pts.size() > sizeBefore) {
+			const int par = tree.parent[newNode];
+			children.emplace_back();
+			edgeLen.push_back(PathR2(tree.pts[par], newState).length);
+			children[par].push_back(newNode);
+			if (bestParent >= 0) {
+				for (int node : nearNodes) {
+					if (node == newNode || node == par)
+						continue;
+					PathR2 pathNewToNear(newState, tree.pts[node]);
+					double through = tree.cost[newNode] + pathNewToNear.length;
+					if (through < tree.cost[node] && prob.IsPathValid(pathNewToNear)) {
+						auto& sib = children[tree.parent[node]];
+						sib.erase(std::find(sib.begin(), sib.end(), node));
+						tree.parent[node] = newNode;
+						children[newNode].push_back(node);
+						edgeLen[node] = pathNewToNear.length;
+						tree.cost[node] = through;
+						std::vector<int> stack { node };
+						while (!stack.empty()) {
+							int q = stack.back();
+							stack.pop_back();
+							for (int c : children[q]) {
+								tree.cost[c] = tree.cost[q] + edgeLen[c];
+								stack.push_back(c);
+							}
+						}
+					}
+				}
+			}
+		}
 		if (newState.x == goal.x && newState.y == goal.y) { // rrt_star.h:136-139, exact equality
 			solution = newNode;
 			res.status = 0;

@@ -13,6 +13,14 @@
 //     check (IsPathValid on the occupancy validator with theta = 0, or StateValidatorFree) are
 //     evaluated by the lanes, the reference's sequential choose-parent scan by thread 0.
 // Independent problems (different seeds / start-goal pairs) map to different workgroups (pp_rrt_run_batch).
+//
+// Beyond the reference: the reference's RRT* only chooses the best parent among the k = ln N nearest
+// nodes -- "FIXME" at rrt_star.h:83; Node::Reparent exists (utils/node.h:203-225) but no planner calls it.  star = 2 / 3 add
+// the missing half of RRT* (Karaman & Frazzoli): after the new node is linked, every near node that gets cheaper through it
+// (and whose connecting edge is valid) is re-parented to it and the saving is carried down its subtree (children lists in
+// HBM, level-synchronous walk by the block).  star = 3 also replaces the k-nearest near-set by a radius search:
+// the <= 16 nearest nodes within gamma * sqrt(ln(n + 1) / (n + 1)).  Parity for these modes is against the oracle's own
+// definition of the same steps (tests/test_gpu_rrt.py); with star = 1 nothing changes.
 #include "pp_search_device.hpp"
 
 #include <algorithm>
@@ -36,7 +44,8 @@ struct RrtArgs {
 	double lbx, lby, ubx, uby;
 	unsigned int maxIteration, maxNumberTreeNode;
 	double maxConnectionDistance, goalBias;
-	int star;
+	int star;          // 0 RRT, 1 RRT* as the reference (choose-parent only), 2 + rewire, 3 + rewire with a radius near-set
+	double gamma;      // star = 3: near-set radius = gamma * sqrt(ln(n + 1) / (n + 1))
 	int capacity;      // allocated nodes per tree
 	int G;             // the spatial index has G x G cells over the bounds
 	double invHx, invHy, hMin; // cells per metre in x / y, smaller cell side
@@ -104,7 +113,8 @@ __device__ __forceinline__ bool edge_valid(const RrtArgs& A, double x0, double y
 }
 
 __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, const RrtProblem* __restrict__ problems, double2* __restrict__ ptsBase, int32_t* __restrict__ parentBase,
-	double* __restrict__ costBase, int32_t* __restrict__ cellHeadBase, int32_t* __restrict__ cellNextBase, RrtOut* __restrict__ outs)
+	double* __restrict__ costBase, int32_t* __restrict__ cellHeadBase, int32_t* __restrict__ cellNextBase, RrtOut* __restrict__ outs, int32_t* __restrict__ childBase,
+	double* __restrict__ edgeLenBase, int32_t* __restrict__ queueBase)
 {
 	// one workgroup = one tree
 	const RrtProblem prob = problems[blockIdx.x];
@@ -114,6 +124,16 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, const RrtProblem* __restr
 	int32_t* const cellHead = cellHeadBase + (size_t)blockIdx.x * A.G * A.G; // -1 = empty (set by the host)
 	int32_t* const cellNext = cellNextBase + (size_t)blockIdx.x * A.capacity;
 	RrtOut* const out = outs + blockIdx.x;
+	// rewire modes only: children lists (first child, next / previous sibling), length of the edge to the parent, two
+	// queues for the subtree walk
+	int32_t* const firstChild = childBase ? childBase + (size_t)blockIdx.x * A.capacity * 3 : nullptr;
+	int32_t* const nextSib = firstChild ? firstChild + A.capacity : nullptr;
+	int32_t* const prevSib = firstChild ? firstChild + 2 * (size_t)A.capacity : nullptr;
+	double* const edgeLen = edgeLenBase ? edgeLenBase + (size_t)blockIdx.x * A.capacity : nullptr;
+	int32_t* const queue0 = queueBase ? queueBase + (size_t)blockIdx.x * A.capacity * 2 : nullptr;
+	int32_t* const queue1 = queue0 ? queue0 + A.capacity : nullptr;
+	const bool rewire = A.star >= 2;
+	__shared__ int s_qn;
 	__shared__ double candD[kCandMax];
 	__shared__ int candI[kCandMax];
 	__shared__ int s_cnt;
@@ -136,7 +156,27 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, const RrtProblem* __restr
 		pts[0] = make_double2(prob.initx, prob.inity); // Tree::CreateRootNode, tree.h:59-65
 		parent[0] = -1;
 		cost[0] = 0.0;
+		if (rewire) {
+			firstChild[0] = nextSib[0] = prevSib[0] = -1;
+			edgeLen[0] = 0.0;
+		}
 	}
+	auto link_child = [&](int p, int c) { // thread 0
+		nextSib[c] = firstChild[p];
+		prevSib[c] = -1;
+		if (firstChild[p] >= 0)
+			prevSib[firstChild[p]] = c;
+		firstChild[p] = c;
+	};
+	auto unlink_child = [&](int c) { // thread 0
+		const int p = parent[c];
+		if (prevSib[c] >= 0)
+			nextSib[prevSib[c]] = nextSib[c];
+		else
+			firstChild[p] = nextSib[c];
+		if (nextSib[c] >= 0)
+			prevSib[nextSib[c]] = prevSib[c];
+	};
 	auto cell_x = [&](double x) { return min(A.G - 1, max(0, (int)((x - A.lbx) * A.invHx))); };
 	auto cell_y = [&](double y) { return min(A.G - 1, max(0, (int)((y - A.lby) * A.invHy))); };
 	auto index_insert = [&](int node, double x, double y) { // thread 0
@@ -416,12 +456,23 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, const RrtProblem* __restr
 			k = kMaxNear;
 		if (k > n)
 			k = n;
+		if (A.star == 3) { // radius search: the <= kMaxNear nearest within the shrinking ball (at least the nearest itself)
+			k = n < kMaxNear ? n : kMaxNear;
+		}
 		nKnn++;
 		if (n <= kBruteMax)
 			brute_knn(nx, ny, k);
 		else
 			grid_knn(nx, ny, k);
-		const int kk = k;
+		int kk = k;
+		if (A.star == 3) {
+			const double np1 = (double)n + 1.0;
+			const double radius = A.gamma * sqrt(log(np1) / np1);
+			int m = 0;
+			while (m < k && nearD[m] <= radius * radius) // ascending distances: the ball's members are a prefix
+				m++;
+			kk = m < 1 ? 1 : m;
+		}
 		// ---- choose parent: lanes evaluate SteerExactly + IsPathValid of every candidate
 		if (tid < kk) {
 			const int node = nearI[tid];
@@ -470,9 +521,75 @@ __global__ void __launch_bounds__(RT) k_rrt(RrtArgs A, const RrtProblem* __restr
 			if (bestParent < 0)
 				nKnn++; // GetNearestNode inside Extend
 		}
-		if (tid == 0)
+		const bool existed = newNode != n - 1 || (p0.x == nx && p0.y == ny);
+		if (tid == 0) {
 			cost[newNode] = bestCost;
+			if (rewire && !existed) {
+				const int par = parent[newNode];
+				const double2 pp = pts[par];
+				const double ex = nx - pp.x, ey = ny - pp.y;
+				edgeLen[newNode] = sqrt(ex * ex + ey * ey);
+				firstChild[newNode] = -1;
+				link_child(par, newNode);
+			}
+		}
 		__syncthreads();
+		if (rewire && !existed && bestParent >= 0) {
+			// ---- rewire (beyond the reference): near nodes that get cheaper through the new node, in near-set order
+			const int par = parent[newNode];
+			if (tid < kk) {
+				const int node = nearI[tid];
+				const double2 p = pts[node];
+				const double dx = p.x - nx, dy = p.y - ny;
+				const double plen = sqrt(dx * dx + dy * dy);
+				candCost[tid] = plen; // edge new -> near
+				candValid[tid] = (node != newNode && node != par && edge_valid(A, nx, ny, p.x, p.y, plen)) ? 1 : 0;
+			}
+			__syncthreads();
+			for (int r = 0; r < kk; r++) {
+				const int node = nearI[r];
+				if (node == newNode || node == par)
+					continue; // (block-uniform)
+				const double through = cost[newNode] + candCost[r];
+				const bool cheaper = through < cost[node];
+				if (cheaper)
+					nEdge++;
+				if (!(cheaper && candValid[r]))
+					continue;
+				if (tid == 0) {
+					unlink_child(node);
+					parent[node] = newNode;
+					link_child(newNode, node);
+					edgeLen[node] = candCost[r];
+					cost[node] = through;
+					queue0[0] = node;
+					s_qn = 0;
+				}
+				__syncthreads();
+				// carry the new cost down the subtree, one level per pass: cost[c] = cost[parent] + edgeLen[c]
+				int cur = 1;
+				int32_t *qa = queue0, *qb = queue1;
+				while (cur > 0) {
+					for (int i = tid; i < cur; i += RT) {
+						const int p = qa[i];
+						const double cp = cost[p];
+						for (int c = firstChild[p]; c >= 0; c = nextSib[c]) {
+							cost[c] = cp + edgeLen[c];
+							qb[atomicAdd(&s_qn, 1)] = c;
+						}
+					}
+					__syncthreads();
+					cur = s_qn;
+					__syncthreads();
+					if (tid == 0)
+						s_qn = 0;
+					int32_t* t = qa;
+					qa = qb;
+					qb = t;
+					__syncthreads();
+				}
+			}
+		}
 		if (nx == prob.goalx && ny == prob.goaly) { // RRTStar::IsSolution: exact equality, rrt_star.h:136-139
 			status = 0;
 			solution = newNode;
@@ -515,6 +632,10 @@ int pp_rrt_run_batch(pp_ctx* ctx, pp_map* map, const double lower[2], const doub
 		set_error("distance grid not uploaded (pp_map_upload_dist2)");
 		return PP_ERR_INVALID;
 	}
+	if (star < 0 || star > 3 || (star == 3 && !(params[4] > 0.0))) {
+		set_error("star: 0 RRT, 1 RRT* (reference), 2 RRT* + rewire, 3 RRT* + rewire + radius near-set (params[4] = gamma > 0)");
+		return PP_ERR_INVALID;
+	}
 	if (!(upper[0] > lower[0]) || !(upper[1] > lower[1])) {
 		set_error("empty bounds");
 		return PP_ERR_INVALID;
@@ -534,6 +655,7 @@ int pp_rrt_run_batch(pp_ctx* ctx, pp_map* map, const double lower[2], const doub
 	A.maxConnectionDistance = params[2];
 	A.goalBias = params[3];
 	A.star = star;
+	A.gamma = star == 3 ? params[4] : 0.0;
 	// the loop stops once size > maxNumberTreeNode or after maxIteration + 1 iterations
 	const unsigned long long cap = std::min<unsigned long long>((unsigned long long)A.maxNumberTreeNode + 2ull, (unsigned long long)A.maxIteration + 3ull);
 	if (cap > (1ull << 28) || cap * (unsigned long long)n_problems > (1ull << 32)) {
@@ -561,6 +683,8 @@ int pp_rrt_run_batch(pp_ctx* ctx, pp_map* map, const double lower[2], const doub
 	int32_t *parent = nullptr, *cellHead = nullptr, *cellNext = nullptr;
 	double* cost = nullptr;
 	RrtOut* dout = nullptr;
+	int32_t *child = nullptr, *queue = nullptr;
+	double* edgeLen = nullptr;
 	const size_t cells = (size_t)A.G * A.G;
 	hipError_t e = hipMalloc((void**)&pts, np * cap * sizeof(double2));
 	if (e == hipSuccess)
@@ -575,6 +699,14 @@ int pp_rrt_run_batch(pp_ctx* ctx, pp_map* map, const double lower[2], const doub
 		e = hipMalloc((void**)&dout, np * sizeof(RrtOut));
 	if (e == hipSuccess)
 		e = hipMalloc((void**)&dprob, np * sizeof(RrtProblem));
+	if (star >= 2) { // children lists, edge lengths and the subtree-walk queues of the rewire modes
+		if (e == hipSuccess)
+			e = hipMalloc((void**)&child, np * cap * 3 * 4);
+		if (e == hipSuccess)
+			e = hipMalloc((void**)&edgeLen, np * cap * 8);
+		if (e == hipSuccess)
+			e = hipMalloc((void**)&queue, np * cap * 2 * 4);
+	}
 	std::vector<RrtOut> ho(np);
 	std::vector<std::unique_ptr<pp_rrt>> rs(np);
 	if (e == hipSuccess)
@@ -582,7 +714,7 @@ int pp_rrt_run_batch(pp_ctx* ctx, pp_map* map, const double lower[2], const doub
 	if (e == hipSuccess)
 		e = hipMemcpyAsync(dprob, probs.data(), np * sizeof(RrtProblem), hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_rrt, dim3(n_problems), dim3(RT), 0, ctx->stream, A, dprob, pts, parent, cost, cellHead, cellNext, dout);
+		hipLaunchKernelGGL(k_rrt, dim3(n_problems), dim3(RT), 0, ctx->stream, A, dprob, pts, parent, cost, cellHead, cellNext, dout, child, edgeLen, queue);
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess)
@@ -609,6 +741,12 @@ int pp_rrt_run_batch(pp_ctx* ctx, pp_map* map, const double lower[2], const doub
 	(void)hipFree(cellHead);
 	(void)hipFree(dout);
 	(void)hipFree(dprob);
+	if (child)
+		(void)hipFree(child);
+	if (edgeLen)
+		(void)hipFree(edgeLen);
+	if (queue)
+		(void)hipFree(queue);
 	if (e != hipSuccess)
 		return pph::hip_fail(e, "pp_rrt_run_batch");
 	for (size_t i = 0; i < np; i++) {

@@ -689,6 +689,10 @@ struct RRTStarParameters {
 	unsigned int maxNumberTreeNode = 1e4;
 	double maxConnectionDistance = 0.1;
 	double goalBias = 0.05;
+	// beyond the reference (its RRT* has no rewire step, rrt_star.h:83): re-parent near nodes through the new node; with
+	// radiusGamma > 0 the near-set is the <= 16 nearest nodes within radiusGamma * sqrt(ln(n + 1) / (n + 1))
+	bool rewire = false;
+	double radiusGamma = 0.0;
 };
 
 /// RRT<Point2d, 2> / RRTStar<Point2d, 2> with PathConnectionR2; validator == nullptr is StateValidatorFree.
@@ -701,10 +705,19 @@ public:
 	void SetSeed(uint64_t s) { m_seed = s; }
 	Status SearchPath() override
 	{
-		const double params[4] = { (double)m_parameters.maxIteration, (double)m_parameters.maxNumberTreeNode, m_parameters.maxConnectionDistance, m_parameters.goalBias };
+		double params[5] = { (double)m_parameters.maxIteration, (double)m_parameters.maxNumberTreeNode, m_parameters.maxConnectionDistance, m_parameters.goalBias, 0.0 };
+		int32_t mode = kStar ? 1 : 0;
+		if constexpr (kStar) {
+			if (m_parameters.radiusGamma > 0.0) {
+				mode = 3;
+				params[4] = m_parameters.radiusGamma;
+			} else if (m_parameters.rewire) {
+				mode = 2;
+			}
+		}
 		pp_rrt* h = nullptr;
 		pp_rrt_result r {};
-		ppCheck(pp_rrt_run(HipContext::Get(), m_validator ? m_validator->Device() : nullptr, m_lb.v, m_ub.v, params, m_init.v, m_goal.v, m_seed, kStar ? 1 : 0, &h, &r));
+		ppCheck(pp_rrt_run(HipContext::Get(), m_validator ? m_validator->Device() : nullptr, m_lb.v, m_ub.v, params, m_init.v, m_goal.v, m_seed, mode, &h, &r));
 		m_path.assign((size_t)r.n_path, Point2d());
 		if (r.n_path)
 			ppCheck(pp_rrt_get(h, nullptr, nullptr, nullptr, &m_path[0].v[0]));

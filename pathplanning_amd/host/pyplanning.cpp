@@ -383,7 +383,9 @@ PYBIND11_MODULE(pyplanning, m)
 		.def_readwrite("max_iteration", &RRTStarParameters::maxIteration)
 		.def_readwrite("max_number_tree_node", &RRTStarParameters::maxNumberTreeNode)
 		.def_readwrite("max_connection_distance", &RRTStarParameters::maxConnectionDistance)
-		.def_readwrite("goal_bias", &RRTStarParameters::goalBias);
+		.def_readwrite("goal_bias", &RRTStarParameters::goalBias)
+		.def_readwrite("rewire", &RRTStarParameters::rewire)
+		.def_readwrite("radius_gamma", &RRTStarParameters::radiusGamma);
 	py::class_<RRTR2>(m, "RRTR2")
 		.def(py::init<const Point2d&, const Point2d&, const Ref<StateValidatorOccupancyMap>&>(), py::arg("lower"), py::arg("upper"), py::arg("validator") = nullptr)
 		.def("set_parameters", &RRTR2::SetParameters)

@@ -606,9 +606,15 @@ class _RRTBase:
     _star = 0
 
     def __init__(self, ctx, lower, upper, validator=None, max_iteration=None, max_number_tree_node=10000, max_connection_distance=0.1,
-                 goal_bias=0.05):
+                 goal_bias=0.05, rewire=False, radius_gamma=None):
+        """rewire / radius_gamma (RRTStar only) go beyond the reference, whose RRT* has no rewire step (rrt_star.h:83): rewire=True
+        re-parents near nodes through the new node and carries the saving down their subtrees; radius_gamma=g also replaces the
+        k-nearest near-set by the <= 16 nearest nodes within g * sqrt(ln(n + 1) / (n + 1))."""
         self.ctx = ctx
         self.lib = ctx.lib
+        if self._star and (rewire or radius_gamma is not None):
+            self._star = 3 if radius_gamma is not None else 2
+        self.gamma = float(radius_gamma) if radius_gamma is not None else 0.0
         self.lower = np.ascontiguousarray(lower, dtype=np.float64)[:2].copy()
         self.upper = np.ascontiguousarray(upper, dtype=np.float64)[:2].copy()
         self.validator = validator
@@ -633,7 +639,7 @@ class _RRTBase:
         self._seed = int(seed)
 
     def search_path(self):
-        params = np.array([self.max_iteration, self.max_number_tree_node, self.max_connection_distance, self.goal_bias], dtype=np.float64)
+        params = np.array([self.max_iteration, self.max_number_tree_node, self.max_connection_distance, self.goal_bias, self.gamma], dtype=np.float64)
         h = C.c_void_p()
         res = _lib.RrtResult()
         mh = self.validator.map.h if self.validator is not None else None
@@ -660,7 +666,7 @@ class _RRTBase:
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         n = len(inits)
         assert goals.shape == inits.shape and seeds.shape == (n,)
-        params = np.array([self.max_iteration, self.max_number_tree_node, self.max_connection_distance, self.goal_bias], dtype=np.float64)
+        params = np.array([self.max_iteration, self.max_number_tree_node, self.max_connection_distance, self.goal_bias, self.gamma], dtype=np.float64)
         hs = (C.c_void_p * n)()
         res = (_lib.RrtResult * n)()
         mh = self.validator.map.h if self.validator is not None else None

@@ -471,10 +471,11 @@ def grid_astar(world, init, goal, bidirectional=False, inner_goal_f=None, inner_
     return dict(status=st.value, cost=cost.value, path=path, explored=ex, explored_reverse=exr)
 
 
-def rrt(world, lb, ub, init, goal, seed, star=False, max_iteration=100, max_nodes=10000, max_connection=0.1, goal_bias=0.05):
+def rrt(world, lb, ub, init, goal, seed, star=False, max_iteration=100, max_nodes=10000, max_connection=0.1, goal_bias=0.05, gamma=0.0):
+    """star: False / 0 RRT, True / 1 RRT* as the reference, 2 = + rewire, 3 = + rewire with the radius near-set (gamma)"""
     lb = np.array(lb, dtype=np.float64)
     ub = np.array(ub, dtype=np.float64)
-    params = np.array([max_iteration, max_nodes, max_connection, goal_bias], dtype=np.float64)
+    params = np.array([max_iteration, max_nodes, max_connection, goal_bias, gamma], dtype=np.float64)
     init = np.array(init, dtype=np.float64)
     goal = np.array(goal, dtype=np.float64)
     lib().ppo_rrt.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_uint64, C.c_int]

@@ -138,3 +138,46 @@ def test_config3_full_size_rrt_star():
     cpu_s = time.time() - t
     same_tree(got, want)
     print("config 3: %d iterations, %d nodes; GPU %.2f s, CPU oracle (brute-force kNN, 1 core) %.1f s" % (got["iterations"], len(nodes), gpu_s, cpu_s))
+
+
+def test_rrt_star_rewire_extension_matches_its_definition():
+    """SURVEY 8f rank 4 (beyond the reference, whose RRT* never rewires): star = 2 (rewire over the k nearest) and star = 3 (radius
+    near-set) on an occupancy map against the oracle's definition of the same steps: identical parents, costs, counters.  And what
+    rewiring is for: tree costs never above, and mostly below, the choose-parent-only tree grown from the same samples."""
+    import pathplanning_amd as pa
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    lb, ub = w.lb[:2], w.ub[:2]
+    kw = dict(max_iteration=4000, max_number_tree_node=4000, max_connection_distance=0.512, goal_bias=0.05)
+    okw = dict(max_iteration=4000, max_nodes=4000, max_connection=0.512, goal_bias=0.05)
+    for seed in (1, 2):
+        plain = pa.RRTStar(ctx, lb, ub, validator=val, **kw)
+        plain.set_init_state([-11.0, -11.0])
+        plain.set_goal_state([100.0, 100.0])  # outside: every iteration runs
+        plain.set_seed(seed)
+        plain.search_path()
+        for mode, extra, oextra in ((2, dict(rewire=True), {}), (3, dict(radius_gamma=6.0), dict(gamma=6.0))):
+            r = pa.RRTStar(ctx, lb, ub, validator=val, **kw, **extra)
+            r.set_init_state([-11.0, -11.0])
+            r.set_goal_state([100.0, 100.0])
+            r.set_seed(seed)
+            r.search_path()
+            want = O.rrt(w, lb, ub, [-11.0, -11.0], [100.0, 100.0], seed, star=mode, **okw, **oextra)
+            same_tree(r.result, want)
+            got = r.result
+            # a tree: every node reaches the root, costs are sums of edge lengths
+            idx = np.arange(1, len(got["nodes"]))
+            fin = np.isfinite(got["costs"][idx])
+            edge = np.hypot(*(got["nodes"][idx] - got["nodes"][got["parents"][idx]]).T)
+            assert np.abs(got["costs"][idx][fin] - (got["costs"][got["parents"][idx]][fin] + edge[fin])).max() < 1e-9
+            depth_ok = np.zeros(len(got["nodes"]), dtype=bool)
+            depth_ok[0] = True
+            for _ in range(len(got["nodes"])):
+                new = depth_ok | depth_ok[np.maximum(got["parents"], 0)]
+                if new.all() or (new == depth_ok).all():
+                    depth_ok = new
+                    break
+                depth_ok = new
+            assert depth_ok.all()
+            if mode == 2:  # same near-sets as the plain run while the trees coincide; rewiring can only lower costs of shared prefixes
+                assert (got["parents"] != plain.result["parents"][:len(got["parents"])]).sum() > 20 or len(got["parents"]) != len(plain.result["parents"])
+                assert np.nanmean(got["costs"][np.isfinite(got["costs"])]) <= np.nanmean(plain.result["costs"][np.isfinite(plain.result["costs"])]) + 1e-9
