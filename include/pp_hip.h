@@ -235,6 +235,9 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
  * available while node records are kept per query (one-query-per-wave kernel).  Any pointer may be NULL. */
 int pp_planner_debug_nodes(pp_planner* planner, int32_t q, int32_t max_nodes, int32_t* parents_host, double* poses_host, double* costs_host,
 	int32_t* dead_host);
+/* ... and per node the action that created it (-1 root, 0..P-1 constant-steer primitive, 1000 + word Reeds-Shepp) and the
+ * length of that edge: with the poses above, the reference's GetGraphSearchExploredPathSet (algo/hybrid_a_star.cpp:186-198). */
+int pp_planner_debug_node_actions(pp_planner* planner, int32_t q, int32_t max_nodes, int32_t* action_host, double* length_host);
 /* Rows the planner's search runs with (k_hybrid_search_rows); 0 = the one-query-per-wave kernel (k_hybrid_search). */
 int pp_planner_search_rows(pp_planner* planner);
 int pp_planner_destroy(pp_planner* planner);

@@ -1621,6 +1621,32 @@ int pp_planner_debug_nodes(pp_planner* planner, int32_t q, int32_t max_nodes, in
 	return PP_OK;
 }
 
+int pp_planner_debug_node_actions(pp_planner* planner, int32_t q, int32_t max_nodes, int32_t* action_host, double* length_host)
+{
+	if (!planner || q < 0 || q >= planner->lastBatch || (int)planner->hostResults.size() <= q || max_nodes < 0) {
+		set_error("no fetched result for this query (call pp_planner_fetch_results first)");
+		return PP_ERR_INVALID;
+	}
+	if (planner->rowsKernel) {
+		set_error("node records are kept per query by the one-query-per-wave kernel only (PP_SEARCH_ROWS=0 or max_batch <= 64)");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	int n = planner->hostResults[q].r.n_nodes;
+	if (n > max_nodes)
+		n = max_nodes;
+	std::vector<Node> nodes(n);
+	if (n)
+		PP_HIP_TRY(hipMemcpy(nodes.data(), planner->nodes + (size_t)q * planner->maxNodes, (size_t)n * sizeof(Node), hipMemcpyDeviceToHost));
+	for (int i = 0; i < n; i++) {
+		if (action_host)
+			action_host[i] = nodes[i].action;
+		if (length_host)
+			length_host[i] = nodes[i].length;
+	}
+	return PP_OK;
+}
+
 int pp_planner_search_rows(pp_planner* planner) { return planner && planner->rowsKernel ? planner->searchRows : 0; }
 
 int pp_planner_set_profiling(pp_planner* planner, int32_t enable)

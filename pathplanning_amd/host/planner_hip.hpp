@@ -12,6 +12,8 @@
 // Everything computes on the GPU; constructing any of the HIP-backed classes without a device throws.
 #pragma once
 
+#include <cstdio>
+
 #include "types.hpp"
 #include "paths.hpp"
 
@@ -635,6 +637,66 @@ public:
 			}
 		}
 		return out;
+	}
+	/// algo/hybrid_a_star.h:229: every edge of the search tree as a path object (also dead leaves, as the reference keeps them);
+	/// single-query planners only (the throughput kernel keeps node records per row, not per query)
+	std::vector<Ref<PathNonHolonomicSE2Base>> GetGraphSearchExploredPathSet() const
+	{
+		std::vector<Ref<PathNonHolonomicSE2Base>> out;
+		const int n = m_last.n_nodes;
+		if (n < 2 || pp_planner_search_rows(m_planner) != 0)
+			return out;
+		std::vector<int32_t> parents((size_t)n), actions((size_t)n);
+		std::vector<Pose2d> poses((size_t)n);
+		std::vector<double> lengths((size_t)n);
+		ppCheck(pp_planner_debug_nodes(m_planner, 0, n, parents.data(), &poses[0].position.v[0], nullptr, nullptr));
+		ppCheck(pp_planner_debug_node_actions(m_planner, 0, n, actions.data(), lengths.data()));
+		auto model = makeRef<KinematicBicycleModel>(m_param.wheelbase, 0.0);
+		const double deltaMax = model->GetSteeringAngleFromTurningRadius(m_param.minTurningRadius);
+		for (int i = 1; i < n; i++) {
+			if (parents[i] < 0)
+				continue;
+			const Pose2d& from = poses[(size_t)parents[i]];
+			if (actions[i] >= 1000) {
+				pp_rs_path rec;
+				ppCheck(pp_rs_connect(HipContext::Get(), 1, &from.position.v[0], &m_goal.position.v[0], m_param.minTurningRadius, (float)m_param.reverseCostMultiplier,
+					(float)m_param.forwardCostMultiplier, (float)m_param.directionSwitchingCost, &rec));
+				out.push_back(makeRef<PathReedsShepp>(rec));
+			} else if (actions[i] >= 0) {
+				const int di = actions[i] / 2;
+				const double delta = di == 0 ? 0.0 : ((di + 1) / 2) / 2.0 * deltaMax * ((di & 1) ? 1.0 : -1.0);
+				out.push_back(makeRef<PathConstantSteer>(model, from, delta, lengths[i], (actions[i] & 1) ? Direction::Backward : Direction::Forward));
+			}
+		}
+		return out;
+	}
+	/// algo/hybrid_a_star.h:247 / heuristics.cpp:167-205: PPM image of the obstacle heuristic of the current goal
+	/// (black = unexplored, brighter = closer to the goal)
+	void VisualizeObstacleHeuristic(const std::string& filename) const
+	{
+		OccupancyMap& map = *m_validator->GetOccupancyMap();
+		const int rows = map.Rows(), cols = map.Columns();
+		std::vector<float> cost((size_t)rows * cols);
+		const double goal[2] = { m_goal.x(), m_goal.y() };
+		ppCheck(pp_obstacle_heuristic(m_validator->Device(), 1, goal, cost.data()));
+		FILE* F = std::fopen(filename.c_str(), "w");
+		if (!F)
+			return;
+		float maxCost = -INFINITY;
+		for (float c : cost)
+			if (c != INFINITY)
+				maxCost = std::max(maxCost, c);
+		std::fprintf(F, "P6\n#\n%d %d\n255\n", rows, cols);
+		for (int y = cols - 1; y >= 0; y--)
+			for (int x = 0; x < rows; x++) {
+				const float c = cost[(size_t)x * cols + y];
+				unsigned char v = 0;
+				if (c != INFINITY) // m_explored
+					v = (unsigned char)std::max(0.0f, std::min((maxCost - c) / maxCost * 255, 255.0f));
+				const unsigned char rgb[3] = { v, v, v };
+				std::fwrite(rgb, 1, 3, F);
+			}
+		std::fclose(F);
 	}
 	double GetGraphSearchOptimalCost() const { return m_last.status == 0 ? m_last.cost : INFINITY; }
 	const Stats& GetStats() const { return m_stats; }

@@ -304,6 +304,8 @@ PYBIND11_MODULE(pyplanning, m)
 		.def("get_graph_search_optimal_cost", &HybridAStar::GetGraphSearchOptimalCost)
 		.def("get_graph_search_path", &HybridAStar::GetGraphSearchPath)
 		.def("get_graph_search_nodes", &HybridAStar::GetGraphSearchNodes)
+		.def("get_graph_search_explored_path_set", &HybridAStar::GetGraphSearchExploredPathSet)
+		.def("visualize_obstacle_heuristic", &HybridAStar::VisualizeObstacleHeuristic)
 		.def("get_smoothed_path", &HybridAStar::GetSmoothedPath)
 		.def_property("smoother_parameters", &HybridAStar::GetSmootherParameters, &HybridAStar::SetSmootherParameters)
 		.def("get_search_parameters", &HybridAStar::GetSearchParameters)

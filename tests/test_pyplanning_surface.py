@@ -20,11 +20,16 @@ def nav():
 
 
 def test_names_match_reference_bindings(nav):
-    for name in ("initialize", "Status", "PathPlannerSE2Base", "HybridAStarSearchParameters", "HybridAStarStats", "HybridAStar", "Point2d", "Pose2d",
-                 "GridCellPosition", "Direction", "StateSpaceSE2", "OccupancyMap", "StateValidatorSE2Base", "StateValidatorOccupancyMap"):
+    # every class / enum the reference module binds (interfaces/python/src/pyplanning.cpp:42-435)
+    for name in ("initialize", "Status", "PathPlannerSE2Base", "HybridAStarSearchParameters", "HybridAStarSmootherParameters", "HybridAStarStats", "SmoothingStatus",
+                 "HybridAStar", "AStarHeuristicN2", "AStarHeuristicFcnN2", "AStarStatePropagatorN2", "AStarStatePropagatorFcnN2", "PathPlannerN2Base", "AStarN2",
+                 "BidirectionalAStarN2", "Point2d", "Pose2d", "GridCellPosition", "Steer", "Direction", "PathSE2Base", "PathSE2", "PathNonHolonomicSE2Base", "PathReedsShepp",
+                 "PathConstantSteer", "KinematicBicycleModel", "PathConnectionSE2Base", "PathConnectionSE2", "PathConnectionReedsShepp", "StateSpaceSE2", "OccupancyMap",
+                 "ObstacleListOccupancyMap", "Obstacle", "Shape", "CompositeShape", "PolygonShape", "RegularPolygonShape", "RectangleShape", "CircleShape",
+                 "StateValidatorSE2Base", "StateValidatorSE2Free", "StateValidatorOccupancyMap", "GVD"):
         assert hasattr(nav, name), name
-    for meth in ("initialize", "set_init_state", "set_goal_state", "search_path", "get_path", "get_stats", "get_graph_search_optimal_cost",
-                 "get_search_parameters", "path_interpolation"):
+    for meth in ("initialize", "set_init_state", "set_goal_state", "search_path", "get_path", "get_stats", "get_graph_search_explored_path_set", "get_graph_search_path",
+                 "get_graph_search_optimal_cost", "get_smoothed_path", "get_search_parameters", "smoother_parameters", "visualize_obstacle_heuristic", "path_interpolation"):
         assert hasattr(nav.HybridAStar, meth), meth
     for meth in ("initialize_size", "rows", "columns", "set_position", "get_position", "get_occupancy_value", "world_position_to_grid_cell", "is_inside_map"):
         assert hasattr(nav.OccupancyMap, meth), meth
@@ -268,6 +273,14 @@ def test_reference_example_script_flow_headless(nav, tmp_path):
     ratios = list(np.linspace(0.0, 1.0, 10))
     for e in edges:
         assert len(e.interpolate(ratios)) == 10
+    # every edge of the search tree (example.py:69-81 plots them) and the obstacle heuristic image
+    explored = algo.get_graph_search_explored_path_set()
+    assert len(explored) >= len(edges) and all(len(e.interpolate(ratios)) == 10 for e in explored[:20])
+    tree_ends = {(round(e.get_final_state().x(), 9), round(e.get_final_state().y(), 9)) for e in explored}
+    assert all((round(n_.x(), 9), round(n_.y(), 9)) in tree_ends for n_ in nodes[1:])
+    img = tmp_path / "heur.ppm"
+    algo.visualize_obstacle_heuristic(str(img))
+    assert img.stat().st_size > 200 * 200 * 3
     # GetPath(): the composite path sampled every 0.8 m, smoothed when the smoother succeeds (hybrid_a_star.cpp:260-303)
     path = algo.get_path()
     stats = algo.get_stats()
