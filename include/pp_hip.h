@@ -256,6 +256,12 @@ typedef struct pp_query_result {
 	int32_t n_rs_attempts;
 	int64_t n_state_checks;
 	int64_t n_path_checks;
+	/* Guard band of the exactness contract: poses of this query (start, children, Reeds-Shepp child) whose
+	 * DiscretizePose (hybrid_a_star.h:104-111) truncated a coordinate within 1e-9 cells of a lattice boundary -- the only places
+	 * where a last-bit libm difference could select another cell.  0: the query's discrete outputs equal the reference's by
+	 * construction; > 0 (e.g. a start or goal placed exactly on a multiple of the resolution): equal as far as observed. */
+	int32_t n_lattice_boundary_hits;
+	int32_t reserved;
 } pp_query_result;
 
 /* Runs the batch (obstacle heuristic + graph search per query).  All pointers host. */

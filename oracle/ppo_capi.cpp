@@ -678,7 +678,7 @@ int ppo_hybrid_search(void* hv, const double* start, const double* goal, uint64_
 	h->last = h->algo->Search(P3(start), P3(goal), seed);
 	return h->last.status;
 }
-/// info = {status, nExpanded, nPathNodes, nNodes, nStateChecks, nPathChecks, nRngDraws, nRsAttempts, nChildren}
+/// info = {status, nExpanded, nPathNodes, nNodes, nStateChecks, nPathChecks, nRngDraws, nRsAttempts, nChildren, nLatticeBoundary}
 void ppo_hybrid_result_info(void* hv, int64_t* info, double* cost)
 {
 	auto* h = (HybridHandle*)hv;
@@ -692,6 +692,7 @@ void ppo_hybrid_result_info(void* hv, int64_t* info, double* cost)
 	info[6] = (int64_t)r.nRngDraws;
 	info[7] = (int64_t)r.nRsAttempts;
 	info[8] = (int64_t)r.nChildren;
+	info[9] = (int64_t)r.nLatticeBoundary;
 	*cost = r.cost;
 }
 void ppo_hybrid_result_expanded(void* hv, int* cells3)

@@ -436,9 +436,11 @@ struct HybridResult {
 	std::vector<int> expandedNode; // node index popped at each expansion
 	std::vector<int> pathNodes; // node indices root..solution
 	uint64_t nStateChecks = 0, nPathChecks = 0, nRngDraws = 0, nRsAttempts = 0, nChildren = 0;
+	uint64_t nLatticeBoundary = 0; // poses discretised within 1e-9 cells of a lattice boundary (instrumentation, not the reference's)
 };
 
 struct HybridAStar {
+	mutable uint64_t nLatticeBoundary = 0;
 	const World* world;
 	HybridParams param;
 	Quirks quirks;
@@ -478,6 +480,9 @@ struct HybridAStar {
 	DiscretePose DiscretizePose(const Pose2d& pose) const
 	{
 		// hybrid_a_star.h:104-111, then the Pose2i constructor (2dplane.h:21-22)
+		const double qx = pose.x / param.spatialResolution, qy = pose.y / param.spatialResolution, qt = pose.WrapTheta() / param.angularResolution;
+		if (std::fabs(qx - std::rint(qx)) < 1e-9 || std::fabs(qy - std::rint(qy)) < 1e-9 || std::fabs(qt - std::rint(qt)) < 1e-9)
+			nLatticeBoundary++;
 		int t = static_cast<int>(pose.WrapTheta() / param.angularResolution);
 		if (quirks.headingAlias)
 			t = AliasHeadingBin(t);
@@ -587,6 +592,7 @@ struct HybridAStar {
 		HybridResult res;
 		Rng rng(seed);
 		const uint64_t sc0 = world->nStateChecks, pc0 = world->nPathChecks;
+		nLatticeBoundary = 0;
 		goalPose = goal;
 		if (!skipObstacleUpdate)
 			obstacle->Update(goal); // hybrid_a_star.cpp:249
@@ -678,6 +684,7 @@ struct HybridAStar {
 		res.nStateChecks = world->nStateChecks - sc0;
 		res.nPathChecks = world->nPathChecks - pc0;
 		res.nRngDraws = rng.draws;
+		res.nLatticeBoundary = nLatticeBoundary;
 		return res;
 	}
 };

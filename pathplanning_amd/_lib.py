@@ -45,7 +45,8 @@ class HybridParams(C.Structure):
 
 class QueryResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_expanded", C.c_int32), ("n_nodes", C.c_int32), ("n_path", C.c_int32), ("cost", C.c_double),
-                ("n_rng_draws", C.c_int32), ("n_rs_attempts", C.c_int32), ("n_state_checks", C.c_int64), ("n_path_checks", C.c_int64)]
+                ("n_rng_draws", C.c_int32), ("n_rs_attempts", C.c_int32), ("n_state_checks", C.c_int64), ("n_path_checks", C.c_int64),
+                ("n_lattice_boundary_hits", C.c_int32), ("reserved", C.c_int32)]
 
 
 # pp_rs_path (include/pp_hip.h): PathReedsShepp as a 128-byte record

@@ -452,14 +452,25 @@ PPD_INLINE int alias_heading_bin(int theta)
 	return t;
 }
 
-/// HybridAStar::StatePropagator::DiscretizePose, algo/hybrid_a_star.h:104-111
-PPD_INLINE void discretize_pose(const Pose& p, const Resolutions& r, int headingAlias, int& ix, int& iy, int& it)
+/// SURVEY 7.3 H2 (guard band): did DiscretizePose truncate a coordinate that lies within 1e-9 cells of a lattice boundary?  There a
+/// last-bit difference between this libm and the reference's could pick the other cell; everywhere else the truncation cannot
+/// differ (observed libm differences are ~1e-16 relative).  The search kernels count such poses per query
+/// (pp_query_result::n_lattice_boundary_hits): the discrete outputs of a query are bit-exact BY CONSTRUCTION when the count is 0.
+PPD_INLINE bool near_integer(double q) { return fabs(q - rint(q)) < 1e-9; }
+
+/// HybridAStar::StatePropagator::DiscretizePose, algo/hybrid_a_star.h:104-111; returns the guard-band flag above
+PPD_INLINE bool discretize_pose(const Pose& p, const Resolutions& r, int headingAlias, int& ix, int& iy, int& it)
 {
-	ix = trunc_to_int(div_by(p.x, r.spatial, r.invSpatial));
-	iy = trunc_to_int(div_by(p.y, r.spatial, r.invSpatial));
-	it = trunc_to_int(div_by(wrap_theta(p.t), r.angular, r.invAngular));
+	const double qx = div_by(p.x, r.spatial, r.invSpatial), qy = div_by(p.y, r.spatial, r.invSpatial), qt = div_by(wrap_theta(p.t), r.angular, r.invAngular);
+	ix = trunc_to_int(qx);
+	iy = trunc_to_int(qy);
+	it = trunc_to_int(qt);
 	if (headingAlias)
 		it = alias_heading_bin(it);
+	return near_integer(qx) | near_integer(qy) | near_integer(qt);
 }
+/// the count rides in the upper bits of the per-lane path-check counter (one reduction, one SuspendRec field for both)
+constexpr int kGuardShift = 44;
+constexpr long long kGuardMask = (1ll << kGuardShift) - 1;
 
 } // namespace ppd

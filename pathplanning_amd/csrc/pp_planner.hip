@@ -285,11 +285,12 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	unsigned int lowS = resume ? 0u : ~0u;
 	int nNodes = resume ? rec.nNodes : 1;
 	unsigned int seq = resume ? rec.seq : 1;
+	bool startOnBoundary = false;
 	if (!resume) {
 		double rs_, rc_;
 		sincos(start.t, &rs_, &rc_);
 		int ix, iy, it;
-		discretize_pose(start, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+		startOnBoundary = discretize_pose(start, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 		uint32_t key = kNoKey;
 		const bool ok = A.ks.pack(ix, iy, it, key);
 		if (lane == 0) {
@@ -330,6 +331,8 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	// this lane's arcs; the totals of the suspended part ride in lane 0
 	long long laneStateChecks = resume && lane == 0 ? rec.stateChecks : 0, lanePathChecks = resume && lane == 0 ? rec.pathChecks : 0;
 	long long rsStateChecks = 0, rsPathChecks = 0;     // wave-uniform (Reeds-Shepp children)
+	if (lane == 0)
+		lanePathChecks += (long long)startOnBoundary << kGuardShift; // (guard band, pp_device.hpp: the count shares this counter's upper bits)
 	int status = -1, solutionNode = -1;
 	double solutionCost = __builtin_huge_val();
 
@@ -577,7 +580,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				a.backward = A.prims.backward[p];
 				child = a.interpolate_sc(1.0, cs, cc);
 				int ix, iy, it;
-				discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+				lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
 				PP_STAMP(PH_HEUR); // [diagnostic: endpoint]
 				// look-ups of the full-length child are issued before the validity march so that their
 				// latency overlaps it (they are redone only when the arc gets truncated)
@@ -606,7 +609,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
 					a.length *= (double)lastValidRatio;
-					discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+					lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
 					if (ix == pix && iy == piy && it == pit)
 						ok = false;
 					else {
@@ -852,7 +855,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
 						const Pose child = path.interpolate(1.0);
 						int ix, iy, it;
-						discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+						lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
 						const double voro = voronoi_cost(m, path, A.rp.voroDiagRes, A.rp.voronoiMult);
 						const double cost = pathAndSwitchingCosts + voro;
 						uint32_t key;
@@ -975,10 +978,13 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		lanePathChecks += __shfl_xor(lanePathChecks, off, 64);
 	}
 	const long long nStateChecks = laneStateChecks + rsStateChecks;
-	const long long pathChecks = lanePathChecks + rsPathChecks;
+	const long long pathChecksPacked = lanePathChecks + rsPathChecks;
+	const long long pathChecks = pathChecksPacked & kGuardMask;
 	__syncthreads();
 	if (lane == 0) {
 		DevResult r;
+		r.r.n_lattice_boundary_hits = (int32_t)(pathChecksPacked >> kGuardShift);
+		r.r.reserved = 0;
 		r.r.status = status;
 		r.r.n_expanded = nExpanded;
 		r.r.n_nodes = nNodes;

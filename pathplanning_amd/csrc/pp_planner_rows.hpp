@@ -291,10 +291,13 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 	};
 	auto finish = [&]() { // writes the result record of the row's query and frees the row
 		const long long nStateChecks = row_sum_i64(laneStateChecks, lane) + rsStateChecks;
-		const long long pathChecks = row_sum_i64(lanePathChecks, lane) + rsPathChecks;
+		const long long pathChecksPacked = row_sum_i64(lanePathChecks, lane) + rsPathChecks;
+		const long long pathChecks = pathChecksPacked & kGuardMask;
 		wave_vmem_sync();
 		if (rl == 0) {
 			DevResult r;
+			r.r.n_lattice_boundary_hits = (int32_t)(pathChecksPacked >> kGuardShift);
+			r.r.reserved = 0;
 			r.r.status = status;
 			r.r.n_expanded = nExpanded;
 			r.r.n_nodes = nNodes;
@@ -451,7 +454,9 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				double rs_, rc_;
 				sincos(start.t, &rs_, &rc_);
 				int ix, iy, it;
-				discretize_pose(start, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+				const bool startOnBoundary = discretize_pose(start, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+				if (rl == 0)
+					lanePathChecks += (long long)startOnBoundary << kGuardShift; // (guard band, pp_device.hpp: the count shares this counter's upper bits)
 				uint32_t key = kNoKey;
 				const bool ok = A.ks.pack(ix, iy, it, key);
 				if (rl == 0) {
@@ -688,7 +693,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				a.backward = A.prims.backward[p];
 				child = a.interpolate_sc(1.0, cs, cc);
 				int ix, iy, it;
-				discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+				lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
 				ROWS_STAMP(11) // endpoint
 				// look-ups of the full-length child are issued before the validity march so that their latency
 				// overlaps it (they are redone only when the arc gets truncated)
@@ -720,7 +725,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
 					a.length *= (double)lastValidRatio;
-					discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+					lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
 					if (ix == pix && iy == piy && it == pit)
 						ok = false;
 					else {
@@ -981,7 +986,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
 						const Pose child = path.interpolate(1.0);
 						int ix, iy, it;
-						discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+						lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
 						const double voro = voronoi_cost(m, path, A.rp.voroDiagRes, A.rp.voronoiMult);
 						const double cost = pathAndSwitchingCosts + voro;
 						uint32_t key;

@@ -369,7 +369,7 @@ class Hybrid:
     def search(self, start, goal, seed=0):
         lib().ppo_hybrid_search.argtypes = [C.c_void_p, _dp, _dp, C.c_uint64]
         status = lib().ppo_hybrid_search(self.h, dptr(arr3(start)), dptr(arr3(goal)), C.c_uint64(seed))
-        info = np.zeros(9, dtype=np.int64)
+        info = np.zeros(10, dtype=np.int64)
         cost = C.c_double()
         lib().ppo_hybrid_result_info(self.h, info.ctypes.data_as(_i64p), C.byref(cost))
         ne, npth = int(info[1]), int(info[2])
@@ -388,7 +388,7 @@ class Hybrid:
         return dict(status=status, cost=cost.value, expanded=expanded, path_poses=poses, path_kind=kind, path_steering=steering,
                     path_length=length, path_direction=direction, path_rsword=rsword, path_cost=pcost, n_nodes=int(info[3]),
                     n_state_checks=int(info[4]), n_path_checks=int(info[5]), n_rng_draws=int(info[6]), n_rs_attempts=int(info[7]),
-                    n_children=int(info[8]))
+                    n_children=int(info[8]), n_lattice_boundary_hits=int(info[9]))
 
 
 SMOOTHER_DEFAULTS = dict(step_tolerance=1e-3, max_iterations=2000, learning_rate=0.01, path_weight=0.0, smooth_weight=0.4, voronoi_weight=0.02,

@@ -35,6 +35,7 @@ def compare(planner, res, h, starts, goals, seeds):
         assert g.n_rs_attempts == r["n_rs_attempts"], q
         assert g.n_state_checks == r["n_state_checks"], (q, g.n_state_checks, r["n_state_checks"])
         assert g.n_path_checks == r["n_path_checks"], (q, g.n_path_checks, r["n_path_checks"])
+        assert g.n_lattice_boundary_hits == r["n_lattice_boundary_hits"], (q, g.n_lattice_boundary_hits, r["n_lattice_boundary_hits"])
         if r["status"] == 0:
             n_ok += 1
             assert abs(g.cost - r["cost"]) < 1e-5
@@ -399,3 +400,28 @@ def test_planners_until_capacity_error_not_an_abort():
         assert got == first
     for p in planners:
         p.close()
+
+
+def test_lattice_guard_band_counter():
+    """the result of every query says how many of its poses were discretised within 1e-9 cells of a lattice
+    boundary (pp_query_result::n_lattice_boundary_hits) -- 0 for random queries (bit-exactness by construction), > 0 when a start
+    sits exactly on a multiple of the resolution (where it holds as observed); the count itself matches the oracle's, through
+    both search kernels."""
+    w, ms, val, ctx = make_pair(192, 4, 31)
+    rng = np.random.RandomState(9)
+    starts = valid_random_poses(rng, w, 12)
+    goals = valid_random_poses(rng, w, 12)
+    on_lattice = 0
+    for q in range(0, 12, 2):  # every other start: x on a lattice line (1.0 = 1 cell), heading on a bin edge
+        cand = np.array([np.round(starts[q][0]), starts[q][1], 0.0])
+        if w.is_state_valid(cand[None, :])[0]:
+            starts[q] = cand
+            on_lattice += 1
+    assert on_lattice >= 2
+    seeds = np.arange(12, dtype=np.uint64) + 900
+    for rows in (0, 8):
+        planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=rows)
+        compare(planner, res, h, starts, goals, seeds)
+        hits = np.array([r.n_lattice_boundary_hits for r in res])
+        assert (hits[1::2] == 0).all(), hits
+        assert (hits[0::2] > 0).sum() >= on_lattice, hits

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # kernel -> (max scratch bytes per lane, max VGPR spills)
 LIMITS = {
     "k_wavefront<false>": (136, 32),
-    "k_hybrid_search_rows": (408, 82),
+    "k_hybrid_search_rows": (416, 84),
     "k_hybrid_search<false>": (112, 0),
     "k_check_states": (0, 0),
     "k_check_states_fused": (0, 0),
