@@ -339,6 +339,31 @@ int pp_rrt_run_batch(pp_ctx* ctx, pp_map* map, const double lower[2], const doub
 int pp_rrt_get(pp_rrt* r, double* nodes_xy, int32_t* parents, double* costs, double* path_xy);
 int pp_rrt_destroy(pp_rrt* r);
 
+/* ---- a12 / f4: AStarN2 and BidirectionalAStarN2 as a batch on the device ------
+ * Engine: algo/a_star.h:326-427 (SearchPath, Expand, ProcessPossibleShortcut; open list order utils/frontier.h:39-48,83-91);
+ * propagator: AStarStatePropagatorFcnN2::GetNeighborStates (algo/a_star_n2.cpp:12-28) over the map's occupancy grid; the user
+ * functions the reference takes (transition cost, heuristic) are fixed to the ones of its own script
+ * (interfaces/python/scripts/example_a_star_grid.py:46-52): Euclidean distance between the two cells, in double.  Other
+ * functions stay on the host engine (pathplanning_amd/host/a_star.hpp), which calls back into the caller per edge as the
+ * reference does.  bidirectional != 0: BidirectionalAStar::SearchPath (algo/bidirectional_a_star.h:130-196) with the
+ * AverageHeuristic pair (:10-39,58-63); inner_goals[q] = {forward heuristic's goal (row, col), reverse heuristic's goal} are the
+ * goals held by the two wrapped heuristic objects, which AverageHeuristic never updates (NULL: forward -> goal, reverse -> init).
+ * cells are (row, col) pairs.  results[q].status: 0 success, -1 failure (open list empty), -2 open list beyond its workspace
+ * (the call then returns PP_ERR_CAPACITY).  paths: [n][max_path][2], root .. goal; in bidirectional mode the meeting cell
+ * appears twice as in the reference (GetPath, :66-72); n_path may exceed max_path (then only the first max_path cells are stored).
+ * expanded / expanded_reverse (optional): [n][max_expanded][2], states in expansion order = GetExploredStates as a sequence
+ * (the root is expanded first; counts may exceed max_expanded likewise). */
+typedef struct pp_grid_result {
+	int32_t status;
+	int32_t n_path;
+	int32_t n_expanded;
+	int32_t n_expanded_reverse;
+	double cost; /* GetOptimalCost; +inf without a path */
+} pp_grid_result;
+int pp_grid_astar_batch(pp_map* map, int32_t n_queries, const int32_t* init_cells, const int32_t* goal_cells, int32_t bidirectional,
+	const int32_t* inner_goals, int32_t max_path, int32_t max_expanded, pp_grid_result* results, int32_t* paths, int32_t* expanded,
+	int32_t* expanded_reverse);
+
 #ifdef __cplusplus
 }
 #endif

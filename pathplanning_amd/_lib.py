@@ -65,6 +65,10 @@ class PostResult(C.Structure):
     _fields_ = [("n_points", C.c_int32), ("smoothing_status", C.c_int32), ("iterations", C.c_int32), ("reserved", C.c_int32), ("length", C.c_double)]
 
 
+class GridResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_path", C.c_int32), ("n_expanded", C.c_int32), ("n_expanded_reverse", C.c_int32), ("cost", C.c_double)]
+
+
 class RrtResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_nodes", C.c_int32), ("n_path", C.c_int32), ("iterations", C.c_int64),
                 ("n_knn_queries", C.c_int64), ("n_edge_checks", C.c_int64)]
@@ -161,6 +165,7 @@ def load():
     L.pp_rrt_run_batch.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, C.c_int32, C.POINTER(vp), C.POINTER(RrtResult)]
     L.pp_rrt_get.argtypes = [vp, vp, vp, vp, vp]
     L.pp_rrt_destroy.argtypes = [vp]
+    L.pp_grid_astar_batch.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.POINTER(GridResult), vp, vp, vp]
     _lib = L
     return L
 

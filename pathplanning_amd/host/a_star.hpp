@@ -432,6 +432,75 @@ private:
 	CellCostFcn m_cost;
 };
 
+/// Many (init, goal) pairs at once on the device (pp_grid_astar_batch, one wave per query): AStarN2 / BidirectionalAStarN2 with
+/// AStarStatePropagatorFcnN2 over the map and the transition cost / heuristic of the reference's own script
+/// (example_a_star_grid.py:46-52: Euclidean distance between the cells).  Same paths, costs and expansion orders as the
+/// host engine above with those functions; any other function needs that engine (per-edge callbacks, as in the reference).
+struct GridSearchResult {
+	Status status = Status::Failure;
+	double cost = std::numeric_limits<double>::infinity(); // GetOptimalCost
+	std::vector<GridCellPosition> path;                    // GetPath (bidirectional: the meeting cell twice, Appendix A Q16)
+	std::vector<GridCellPosition> expanded, expandedReverse; // expansion order = GetExploredStates as a sequence
+};
+class GridAStarBatchHip {
+public:
+	explicit GridAStarBatchHip(const Ref<OccupancyMap>& map) : m_map(map) { }
+	/// innerGoals (bidirectional only, optional): per query the goals held by the two heuristics the AverageHeuristic pair wraps
+	/// {forward, reverse}; default forward -> goal, reverse -> init
+	std::vector<GridSearchResult> SearchBatch(const std::vector<GridCellPosition>& inits, const std::vector<GridCellPosition>& goals, bool bidirectional = false,
+		bool wantExpanded = true, const std::vector<std::pair<GridCellPosition, GridCellPosition>>* innerGoals = nullptr)
+	{
+		if (inits.size() != goals.size() || (innerGoals && innerGoals->size() != inits.size()))
+			throw std::invalid_argument("GridAStarBatchHip::SearchBatch: one goal (and one inner-goal pair) per init");
+		const int n = (int)inits.size();
+		std::vector<GridSearchResult> out((size_t)n);
+		if (n == 0)
+			return out;
+		const int rows = m_map->Rows(), cols = m_map->Columns();
+		const int maxPath = std::min<long long>((long long)rows * cols + 1, 4ll * (rows + cols));
+		const int maxExpanded = wantExpanded ? rows * cols : 0;
+		std::vector<int32_t> ic((size_t)n * 2), gc((size_t)n * 2), ig;
+		for (int i = 0; i < n; i++) {
+			ic[2 * i] = inits[i].row, ic[2 * i + 1] = inits[i].col;
+			gc[2 * i] = goals[i].row, gc[2 * i + 1] = goals[i].col;
+		}
+		if (innerGoals) {
+			ig.resize((size_t)n * 4);
+			for (int i = 0; i < n; i++) {
+				ig[4 * i] = (*innerGoals)[i].first.row, ig[4 * i + 1] = (*innerGoals)[i].first.col;
+				ig[4 * i + 2] = (*innerGoals)[i].second.row, ig[4 * i + 3] = (*innerGoals)[i].second.col;
+			}
+		}
+		std::vector<pp_grid_result> res((size_t)n);
+		std::vector<int32_t> paths((size_t)n * maxPath * 2), exp((size_t)n * maxExpanded * 2), expR(bidirectional ? (size_t)n * maxExpanded * 2 : 0);
+		ppCheck(pp_grid_astar_batch(m_map->Device(), n, ic.data(), gc.data(), bidirectional ? 1 : 0, innerGoals ? ig.data() : nullptr, maxPath, maxExpanded, res.data(),
+			paths.data(), wantExpanded ? exp.data() : nullptr, wantExpanded && bidirectional ? expR.data() : nullptr));
+		auto cells = [](const int32_t* p, int count) {
+			std::vector<GridCellPosition> v;
+			v.reserve((size_t)count);
+			for (int k = 0; k < count; k++)
+				v.emplace_back(p[2 * k], p[2 * k + 1]);
+			return v;
+		};
+		for (int i = 0; i < n; i++) {
+			if (res[i].n_path > maxPath)
+				throw std::runtime_error("GridAStarBatchHip: path longer than 4 * (rows + columns) cells");
+			out[i].status = res[i].status == 0 ? Status::Success : Status::Failure;
+			out[i].cost = res[i].cost;
+			out[i].path = cells(&paths[(size_t)i * maxPath * 2], res[i].n_path);
+			if (wantExpanded) {
+				out[i].expanded = cells(&exp[(size_t)i * maxExpanded * 2], res[i].n_expanded);
+				if (bidirectional)
+					out[i].expandedReverse = cells(&expR[(size_t)i * maxExpanded * 2], res[i].n_expanded_reverse);
+			}
+		}
+		return out;
+	}
+
+private:
+	Ref<OccupancyMap> m_map;
+};
+
 using AStarHeuristicFcnN2 = AStarConcreteHeuristicFcn<GridCellPosition, CellCostFcn>; // a_star_n2.h:26
 using PathPlannerN2Base = PathPlanner<GridCellPosition>; // path_planner.h:43
 using AStarN2 = AStar<GridCellPosition, NullAction>; // a_star_n2.h:29-34

@@ -374,6 +374,21 @@ PYBIND11_MODULE(pyplanning, m)
 		.def("get_expansion_orders", &BidirectionalAStarN2::GetExpansionOrders)
 		.def("get_optimal_cost", &BidirectionalAStarN2::GetOptimalCost);
 
+	// beyond the reference's module: the same two searches for many (init, goal) pairs on the device (Euclidean cost / heuristic)
+	py::class_<GridSearchResult>(m, "GridSearchResult")
+		.def_readonly("status", &GridSearchResult::status)
+		.def_readonly("cost", &GridSearchResult::cost)
+		.def_readonly("path", &GridSearchResult::path)
+		.def_readonly("expanded", &GridSearchResult::expanded)
+		.def_readonly("expanded_reverse", &GridSearchResult::expandedReverse);
+	py::class_<GridAStarBatchHip>(m, "GridAStarBatch")
+		.def(py::init<const Ref<OccupancyMap>&>())
+		.def("search_batch",
+			[](GridAStarBatchHip& self, const std::vector<GridCellPosition>& inits, const std::vector<GridCellPosition>& goals, bool bidirectional, bool wantExpanded) {
+				return self.SearchBatch(inits, goals, bidirectional, wantExpanded);
+			},
+			py::arg("inits"), py::arg("goals"), py::arg("bidirectional") = false, py::arg("want_expanded") = true);
+
 	py::class_<RRTParameters>(m, "RRTParameters")
 		.def(py::init<>())
 		.def_readwrite("max_iteration", &RRTParameters::maxIteration)

@@ -692,3 +692,48 @@ class RRT(_RRTBase):
 
 class RRTStar(_RRTBase):
     _star = 1
+
+
+class GridAStarBatch:
+    """AStarN2 / BidirectionalAStarN2 (algo/a_star_n2.h, algo/bidirectional_a_star.h) for many (init, goal) pairs at once, one wave per
+    query on the device, with the transition cost and heuristic of the reference's script (example_a_star_grid.py:46-52: Euclidean
+    distance between cells).  Other cost / heuristic functions run on the host engine (pyplanning.AStarN2, per-edge callbacks as in
+    the reference)."""
+
+    def __init__(self, map_set):
+        self.map = map_set
+        self.lib = map_set.lib
+
+    def search_batch(self, inits, goals, bidirectional=False, inner_goals=None, max_path=None, max_expanded=None, want_expanded=True):
+        """inits / goals: [n][2] (row, col).  inner_goals [n][4] (bidirectional only): the goals held by the two heuristics the
+        AverageHeuristic pair wraps (default: forward -> goal, reverse -> init).  Returns one dict per query: status, cost, path
+        [(row, col)], expanded (expansion order; + expanded_reverse when bidirectional)."""
+        inits = np.ascontiguousarray(inits, dtype=np.int32).reshape(-1, 2)
+        goals = np.ascontiguousarray(goals, dtype=np.int32).reshape(-1, 2)
+        n = len(inits)
+        assert goals.shape == inits.shape
+        cells = self.map.rows * self.map.cols
+        max_path = int(max_path) if max_path is not None else min(cells + 1, 4 * (self.map.rows + self.map.cols))
+        max_expanded = int(max_expanded) if max_expanded is not None else (cells if want_expanded else 0)
+        ig = None
+        if inner_goals is not None:
+            ig = np.ascontiguousarray(inner_goals, dtype=np.int32).reshape(n, 4)
+        res = (_lib.GridResult * max(n, 1))()
+        paths = np.zeros((n, max_path, 2), dtype=np.int32)
+        exp = np.zeros((n, max_expanded, 2), dtype=np.int32) if want_expanded else None
+        expr = np.zeros((n, max_expanded, 2), dtype=np.int32) if want_expanded and bidirectional else None
+        check(self.lib.pp_grid_astar_batch(self.map.h, n, ptr(inits), ptr(goals), 1 if bidirectional else 0, ptr(ig) if ig is not None else None,
+                                           max_path, max_expanded if want_expanded else 0, res, ptr(paths), ptr(exp) if exp is not None else None,
+                                           ptr(expr) if expr is not None else None))
+        out = []
+        for i in range(n):
+            r = res[i]
+            if r.n_path > max_path or (want_expanded and max(r.n_expanded, r.n_expanded_reverse) > max_expanded):
+                raise _lib.PPError("query %d: path (%d) or expansion list (%d) longer than the buffers" % (i, r.n_path, r.n_expanded))
+            d = dict(status=r.status, cost=r.cost, path=paths[i, :r.n_path].copy(), n_expanded=r.n_expanded, n_expanded_reverse=r.n_expanded_reverse)
+            if want_expanded:
+                d["expanded"] = exp[i, :r.n_expanded].copy()
+                if bidirectional:
+                    d["expanded_reverse"] = expr[i, :r.n_expanded_reverse].copy()
+            out.append(d)
+        return out

@@ -24,6 +24,7 @@ LIMITS = {
     "k_nonholo_build": (0, 0),
     "k_knn": (0, 0),
     "k_rrt": (0, 0),
+    "k_grid_astar": (0, 0),
 }
 
 
