@@ -271,6 +271,11 @@ int pp_planner_search_batch(pp_planner* planner, int32_t n_queries, const double
 int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const double* starts_dev, const double* goals_dev,
 	const uint64_t* seeds_dev);
 int pp_planner_fetch_results(pp_planner* planner, int32_t n_queries, pp_query_result* results_host);
+/* Throughput use, several planners with a batch in flight each (own stream each): the NEXT pp_planner_search_batch*_dev of `planner`
+ * starts on the device only when the obstacle-heuristic fields of `predecessor`'s most recently launched batch are built (one-shot,
+ * cleared by that call).  Batches launched together otherwise run in phase -- all wavefronts, then all searches, then all tails of long
+ * queries with the GPU nearly empty; started one wavefront apart they interleave.  Scheduling only: results do not depend on it. */
+int pp_planner_start_after_fields_of(pp_planner* planner, pp_planner* predecessor);
 /* Solution path of query q: poses (3*n_path doubles), per-node action kind (0 root, 1 arc, 2 Reeds-Shepp),
  * primitive index (arc) or RS word, arc length; expanded: cells in expansion order (3*n_expanded ints). Any pointer may be NULL. */
 int pp_planner_get_path(pp_planner* planner, int32_t q, double* poses_host, int32_t* kind_host, int32_t* prim_host, double* length_host,

@@ -165,6 +165,7 @@ def load():
     L.pp_rrt_run_batch.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, C.c_int32, C.POINTER(vp), C.POINTER(RrtResult)]
     L.pp_rrt_get.argtypes = [vp, vp, vp, vp, vp]
     L.pp_rrt_destroy.argtypes = [vp]
+    L.pp_planner_start_after_fields_of.argtypes = [vp, vp]
     L.pp_grid_astar_batch.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp, C.c_int32, C.c_int32, C.POINTER(GridResult), vp, vp, vp]
     _lib = L
     return L

@@ -1048,6 +1048,7 @@ struct pp_planner {
 	double *dStarts = nullptr, *dGoals = nullptr;
 	uint64_t* dSeeds = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+	hipEvent_t startAfter = nullptr; // one-shot: the next batch waits for this event (pp_planner_start_after_fields_of)
 	// the probable longest queries of a batch run one per wave next to the rows kernel (PP_SEARCH_DIRECT), on their own stream
 	hipStream_t directStream = nullptr;
 	hipEvent_t e3 = nullptr;
@@ -1446,6 +1447,16 @@ int pp_planner_set_nonholo_table(pp_planner* planner, const double* table_host)
 	return PP_OK;
 }
 
+int pp_planner_start_after_fields_of(pp_planner* planner, pp_planner* predecessor)
+{
+	if (!planner || !predecessor || planner == predecessor || planner->map->ctx->device != predecessor->map->ctx->device) {
+		set_error("two different planners on the same device");
+		return PP_ERR_INVALID;
+	}
+	planner->startAfter = predecessor->e1; // recorded behind the predecessor's wavefront launch; never recorded = no wait
+	return PP_OK;
+}
+
 int pp_planner_get_nonholo_table(pp_planner* planner, double* table_host)
 {
 	if (!planner || !table_host || !planner->tableReady) {
@@ -1473,6 +1484,10 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 	hipStream_t s = planner->map->ctx->stream;
 	planner->args.m = planner->map->view(); // validator tunables may have changed
 	const MapView& m = planner->args.m;
+	if (planner->startAfter) { // phase this batch behind another planner's (throughput use, several batches in flight)
+		PP_HIP_TRY(hipStreamWaitEvent(s, planner->startAfter, 0));
+		planner->startAfter = nullptr;
+	}
 	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 32, s)); // the step's only fill: every counter of every kernel
 	PP_HIP_TRY(hipEventRecord(planner->e0, s));
 	// the rows kernel hands the queries out longest-first (order written by the wavefront kernel's last workgroup)

@@ -498,6 +498,11 @@ class HybridAStarBatch:
         self._n = n
         return res
 
+    def start_after_fields_of(self, predecessor):
+        """the next batch of this planner starts on the device once `predecessor`'s current batch has its heuristic fields (one-shot):
+        phases the batches in flight one wavefront apart instead of letting them run in step (scheduling only)"""
+        check(self.lib.pp_planner_start_after_fields_of(self.h, predecessor.h))
+
     def search_batch_dev(self, starts_t, goals_t, seeds_t):
         n = starts_t.numel() // 3
         check(self.lib.pp_planner_search_batch_dev(self.h, n, _dev_ptr(starts_t), _dev_ptr(goals_t), _dev_ptr(seeds_t)))
