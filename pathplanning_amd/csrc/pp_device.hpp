@@ -19,12 +19,19 @@ constexpr double kPi = 3.14159265358979323846;
 // 256 contiguous bytes): the wavefront writes each cell once, in ring order, and a ring crosses a tile in a few
 // consecutive rounds, so the four lines of a tile fill up while they are still in L2 instead of one write-back
 // per 4-byte store (row-major: a vertical or diagonal front touches a different line for every cell).
+#ifndef PP_FIELD_TILE_LOG2
+#define PP_FIELD_TILE_LOG2 3 // 8 x 8 cells; (experiment) 2 = 4 x 4 cells, one cache line per tile
+#endif
+constexpr int kFieldTileLog2 = PP_FIELD_TILE_LOG2, kFieldTile = 1 << kFieldTileLog2, kFieldTileMask = kFieldTile - 1;
 __host__ __device__ inline size_t field_tiled_index(int cols, int row, int col)
 {
-	const int tpr = (cols + 7) >> 3;
-	return ((size_t)((row >> 3) * tpr + (col >> 3)) << 6) | (size_t)(((row & 7) << 3) | (col & 7));
+	const int tpr = (cols + kFieldTileMask) >> kFieldTileLog2;
+	return ((size_t)((row >> kFieldTileLog2) * tpr + (col >> kFieldTileLog2)) << (2 * kFieldTileLog2)) | (size_t)(((row & kFieldTileMask) << kFieldTileLog2) | (col & kFieldTileMask));
 }
-__host__ __device__ inline size_t field_tiled_elems(int rows, int cols) { return (size_t)((rows + 7) >> 3) * (size_t)((cols + 7) >> 3) * 64; }
+__host__ __device__ inline size_t field_tiled_elems(int rows, int cols)
+{
+	return (size_t)((rows + kFieldTileMask) >> kFieldTileLog2) * (size_t)((cols + kFieldTileMask) >> kFieldTileLog2) * (size_t)(kFieldTile * kFieldTile);
+}
 constexpr double kPi2 = 1.57079632679489661923;
 
 struct Pose {

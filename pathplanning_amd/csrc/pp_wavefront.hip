@@ -241,6 +241,22 @@ __device__ __forceinline__ Row3 load_row3(const uint32_t* p)
 
 constexpr uint32_t ST_FREE = 0u, ST_OCC = 1u, ST_SEEN = 2u; // state grid values (border = ST_OCC)
 
+// experiment switches (tools/build_variant.py): the cost field is written once per cell and never read by this kernel
+#ifndef PP_WF_NT_COST
+#define PP_WF_NT_COST 0
+#endif
+#ifndef PP_WF_NT_FILL
+#define PP_WF_NT_FILL 0
+#endif
+__device__ __forceinline__ void store_cost(float* p, float v)
+{
+#if PP_WF_NT_COST
+	__builtin_nontemporal_store(v, p);
+#else
+	*p = v;
+#endif
+}
+
 /// Candidate mask of a window cell from the 3x3 block of states around it (heuristics.cpp:127-136):
 /// neighbour j is offered iff it is free and undiscovered and the corner rule allows the move.
 __device__ __forceinline__ uint32_t candidate_mask(const Row3& up, const Row3& mid, const Row3& dn)
@@ -563,8 +579,15 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		{
 			uint4* c4 = reinterpret_cast<uint4*>(cost); // fieldElems * 4 bytes is a multiple of 16 when tiled; row-major: tail below
 			const int64_t n4 = fieldElems >> 2;
+#if PP_WF_NT_FILL
+			typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+			const u32x4 inf4 = { kInfBits, kInfBits, kInfBits, kInfBits };
+			for (int64_t i = tid; i < n4; i += WF_T)
+				__builtin_nontemporal_store(inf4, reinterpret_cast<u32x4*>(cost) + i);
+#else
 			for (int64_t i = tid; i < n4; i += WF_T)
 				c4[i] = make_uint4(kInfBits, kInfBits, kInfBits, kInfBits);
+#endif
 			for (int64_t i = (n4 << 2) + tid; i < fieldElems; i += WF_T)
 				reinterpret_cast<uint32_t*>(cost)[i] = kInfBits;
 		}
@@ -945,7 +968,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						const uint32_t pb = __float_as_uint(pathCost);
 						const int nr = (int)(ncell >> 16), nc = (int)(ncell & 0xFFFFu);
 						state[st_addr(tpr, nr, nc)] = (uint8_t)ST_SEEN;
-						cost[out_index(nr - 1, nc - 1)] = pathCost;
+						store_cost(&cost[out_index(nr - 1, nc - 1)], pathCost);
 						newMin = min(newMin, pb);
 						push_entry(slot++, ncell, pb);
 					}
@@ -1046,7 +1069,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 							const float pathCost = transitionCost + ci; // heuristics.cpp:135
 							const uint32_t pb = __float_as_uint(pathCost);
 							state[st_addr(tpr, pr + kDr[j], pcc + kDc[j])] = (uint8_t)ST_SEEN;
-							cost[out_index(pr - 1 + kDr[j], pcc - 1 + kDc[j])] = pathCost;
+							store_cost(&cost[out_index(pr - 1 + kDr[j], pcc - 1 + kDc[j])], pathCost);
 							newMin = min(newMin, pb);
 							push_entry(slot++, ncell, pb);
 						}

@@ -425,3 +425,29 @@ def test_lattice_guard_band_counter():
         hits = np.array([r.n_lattice_boundary_hits for r in res])
         assert (hits[1::2] == 0).all(), hits
         assert (hits[0::2] > 0).sum() >= on_lattice, hits
+
+
+def test_chained_planners_give_the_same_results():
+    """pp_planner_start_after_fields_of is scheduling only: two planners on their own streams, the second one's batch held back until
+    the first one's heuristic fields are built, return what they return unchained; chaining a planner to itself is refused."""
+    import pathplanning_amd as pa
+    from pathplanning_amd import _lib, synthetic
+    w, ms, val, ctx = make_pair(192, 4, 31)
+    rng = np.random.RandomState(12)
+    starts = valid_random_poses(rng, w, 24)
+    goals = valid_random_poses(rng, w, 24)
+    seeds = np.arange(24, dtype=np.uint64) + 77
+    base = pa.HybridAStarBatch(val, pa.HybridAStarSearchParameters(), max_batch=24, max_nodes=32768, search_rows=8)
+    base.initialize()
+    want = base.search_batch(starts, goals, seeds)
+    ctx2 = pa.Context(0)
+    m = dict(lower=w.lb, upper=w.ub, resolution=0.1, occ=w.occ(), d2=w.d2(), path_cost=w.pathcost())
+    ms2, val2 = synthetic.upload(ctx2, m)
+    other = pa.HybridAStarBatch(val2, pa.HybridAStarSearchParameters(), max_batch=24, max_nodes=32768, search_rows=8)
+    other.initialize(base.nonholo_table())
+    other.start_after_fields_of(base)  # base has a recorded "fields built" event from the batch above
+    got = other.search_batch(starts, goals, seeds)
+    for a, b in zip(want, got):
+        assert (a.status, a.n_expanded, a.n_nodes, a.n_path) == (b.status, b.n_expanded, b.n_nodes, b.n_path) and (a.cost == b.cost or a.status != 0)
+    with pytest.raises(_lib.PPError):
+        other.start_after_fields_of(other)
