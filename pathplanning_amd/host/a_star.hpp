@@ -445,10 +445,11 @@ struct GridSearchResult {
 class GridAStarBatchHip {
 public:
 	explicit GridAStarBatchHip(const Ref<OccupancyMap>& map) : m_map(map) { }
+	/// wantExpanded: also return the expansion orders ([n][rows * columns] cells of buffer per direction: for small batches / maps);
 	/// innerGoals (bidirectional only, optional): per query the goals held by the two heuristics the AverageHeuristic pair wraps
 	/// {forward, reverse}; default forward -> goal, reverse -> init
 	std::vector<GridSearchResult> SearchBatch(const std::vector<GridCellPosition>& inits, const std::vector<GridCellPosition>& goals, bool bidirectional = false,
-		bool wantExpanded = true, const std::vector<std::pair<GridCellPosition, GridCellPosition>>* innerGoals = nullptr)
+		bool wantExpanded = false, const std::vector<std::pair<GridCellPosition, GridCellPosition>>* innerGoals = nullptr)
 	{
 		if (inits.size() != goals.size() || (innerGoals && innerGoals->size() != inits.size()))
 			throw std::invalid_argument("GridAStarBatchHip::SearchBatch: one goal (and one inner-goal pair) per init");

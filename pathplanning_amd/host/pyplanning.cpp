@@ -387,7 +387,7 @@ PYBIND11_MODULE(pyplanning, m)
 			[](GridAStarBatchHip& self, const std::vector<GridCellPosition>& inits, const std::vector<GridCellPosition>& goals, bool bidirectional, bool wantExpanded) {
 				return self.SearchBatch(inits, goals, bidirectional, wantExpanded);
 			},
-			py::arg("inits"), py::arg("goals"), py::arg("bidirectional") = false, py::arg("want_expanded") = true);
+			py::arg("inits"), py::arg("goals"), py::arg("bidirectional") = false, py::arg("want_expanded") = false);
 
 	py::class_<RRTParameters>(m, "RRTParameters")
 		.def(py::init<>())

@@ -709,15 +709,18 @@ class GridAStarBatch:
         self.map = map_set
         self.lib = map_set.lib
 
-    def search_batch(self, inits, goals, bidirectional=False, inner_goals=None, max_path=None, max_expanded=None, want_expanded=True):
+    def search_batch(self, inits, goals, bidirectional=False, inner_goals=None, max_path=None, max_expanded=None, want_expanded=None):
         """inits / goals: [n][2] (row, col).  inner_goals [n][4] (bidirectional only): the goals held by the two heuristics the
         AverageHeuristic pair wraps (default: forward -> goal, reverse -> init).  Returns one dict per query: status, cost, path
-        [(row, col)], expanded (expansion order; + expanded_reverse when bidirectional)."""
+        [(row, col)], n_expanded and -- want_expanded (default: while n * cells <= 2^26) -- expanded (expansion order; + expanded_reverse
+        when bidirectional)."""
         inits = np.ascontiguousarray(inits, dtype=np.int32).reshape(-1, 2)
         goals = np.ascontiguousarray(goals, dtype=np.int32).reshape(-1, 2)
         n = len(inits)
         assert goals.shape == inits.shape
         cells = self.map.rows * self.map.cols
+        if want_expanded is None:  # the expansion orders are [n][cells][2] int32 per direction: only while that stays small
+            want_expanded = max_expanded is not None or n * cells <= (1 << 26)
         max_path = int(max_path) if max_path is not None else min(cells + 1, 4 * (self.map.rows + self.map.cols))
         max_expanded = int(max_expanded) if max_expanded is not None else (cells if want_expanded else 0)
         ig = None

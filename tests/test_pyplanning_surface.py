@@ -351,14 +351,14 @@ def test_reference_grid_example_script_flow_headless(nav):
     batch = nav.GridAStarBatch(m)
     inits = [nav.GridCellPosition(1, 1), nav.GridCellPosition(35, 35), nav.GridCellPosition(3, 30)]
     goals = [nav.GridCellPosition(35, 35), nav.GridCellPosition(1, 1), nav.GridCellPosition(30, 3)]
-    res = batch.search_batch(inits, goals)
+    res = batch.search_batch(inits, goals, want_expanded=True)
     assert res[0].status == nav.Status.SUCCESS and res[0].cost == uni.get_optimal_cost()
     assert [(c.row, c.col) for c in res[0].path] == [(c.row, c.col) for c in uni.get_path()]
     assert [(c.row, c.col) for c in res[0].expanded] == [(c.row, c.col) for c in uni.get_expansion_order()]
     for q in range(3):
         want_q = O.grid_astar(w, (inits[q].row, inits[q].col), (goals[q].row, goals[q].col))
         assert [(c.row, c.col) for c in res[q].path] == [tuple(c) for c in want_q["path"]] and res[q].cost == want_q["cost"]
-    resb = batch.search_batch(inits, goals, bidirectional=True)
+    resb = batch.search_batch(inits, goals, bidirectional=True, want_expanded=True)
     for q in range(3):
         want_q = O.grid_astar(w, (inits[q].row, inits[q].col), (goals[q].row, goals[q].col), bidirectional=True,
                               inner_goal_f=(goals[q].row, goals[q].col), inner_goal_r=(inits[q].row, inits[q].col))
