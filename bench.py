@@ -68,11 +68,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        # rehearsal on a one-GPU box: PP_BENCH_BACKEND=gloo PP_BENCH_DEVICE=0 runs the N-rank code path with every rank on device 0
+        dist.init_process_group(backend=os.environ.get("PP_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     n_gpus = max(world, 1)
     if args.gpus != n_gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
                          "--master-port P bench.py --gpus N ...` (one rank per GPU)" % (args.gpus, n_gpus))
+    local_rank = int(os.environ.get("PP_BENCH_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
