@@ -2,6 +2,8 @@
 tests).  Queries are independent given the read-only map set, so there is NO data-path collective: each rank plans
 its own queries.  Communication happens twice: one broadcast of the map set when it is loaded on one rank only, and one gather
 of fixed-size result records {status, cost, nExpanded, nPoses, poses[max_poses] x 3} at the end of a batch."""
+import ctypes as C
+
 import numpy as np
 
 RECORD_FIELDS = ("status", "cost", "n_expanded", "n_path")
@@ -22,6 +24,11 @@ def records_from_results(results, n, planner=None, max_poses=0):
     """One float64 row per local query: status, cost, n_expanded, n_path, then (when max_poses > 0) the first max_poses path
     poses (x, y, theta), zero-padded.  `planner` needs get_path_of(q) -> {"poses": (k, 3)} (HybridAStarBatch has it)."""
     rec = np.zeros((n, record_width(max_poses)), dtype=np.float64)
+    if isinstance(results, C.Array) and n > 0:  # the planner's own result array: one vectorised pass (4096 records per batch and lane)
+        a = np.frombuffer(results, dtype=np.dtype(type(results[0])), count=n)
+        rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3] = a["status"], a["cost"], a["n_expanded"], a["n_path"]
+        if not (max_poses and planner is not None):
+            return rec
     for i in range(n):
         r = results[i]
         rec[i, :4] = (r.status, r.cost, r.n_expanded, r.n_path)
