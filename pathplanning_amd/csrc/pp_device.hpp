@@ -137,6 +137,46 @@ PPD_INLINE bool is_state_valid(const MapView& m, double x, double y, double thet
 	return distance >= m.minSafeRadius;
 }
 
+/// Obstacle-distance window around an expanded node (one-query search kernel): every sample of the node's constant-steer children
+/// lies within the arc length (1.5 x the spatial resolution) of its pose, so the (2 * kDistWinHalf + 1)^2 cells around the pose's
+/// cell are fetched into LDS in ONE memory round trip when the node is popped; the children's adaptive marches -- a chain of
+/// dependent distance reads, two to four per expansion -- then read LDS.  Same values, same arithmetic: only where they are read from.
+constexpr int kDistWinHalf = 16, kDistWin = 2 * kDistWinHalf + 1, kDistWinElems = ((kDistWin * kDistWin + 63) / 64) * 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(3))) float* LdsFloatPtr; // an LDS pointer the compiler KNOWS to be one: ds_read, and no
+                                                                      // select between an LDS-derived and a global generic address
+#else
+typedef const float* LdsFloatPtr;
+#endif
+struct DistWindow {
+	LdsFloatPtr win; // LDS, row-major kDistWin x kDistWin, cell (r0 + i, c0 + j) at i * kDistWin + j
+	int r0, c0;
+	PPD_INLINE float fetch(const MapView& m, int row, int col) const
+	{
+		const unsigned wr = (unsigned)(row - r0), wc = (unsigned)(col - c0);
+		if (wr < (unsigned)kDistWin && wc < (unsigned)kDistWin)
+			return win[wr * kDistWin + wc];
+		return m.dist[(size_t)row * m.cols + col]; // (arcs longer than the window: never with the reference's 1.5 m arcs at 0.1 m cells)
+	}
+};
+PPD_INLINE bool is_state_valid(const MapView& m, const DistWindow& w, double x, double y, double theta, float& distance)
+{
+	const double lx = x - m.lox, ly = y - m.loy;
+	const double lt = wrap_theta(theta);
+	int row, col;
+	world_to_cell(m, x, y, row, col);
+	if (lx < m.lbx || lx > m.ubx)
+		return false;
+	if (ly < m.lby || ly > m.uby)
+		return false;
+	if (lt < m.lbt || lt > m.ubt)
+		return false;
+	if (!inside_map(m, row, col))
+		return false;
+	distance = w.fetch(m, row, col);
+	return distance >= m.minSafeRadius;
+}
+
 /// is_state_valid in two halves, so that the caller can put other work between the load and its first use (a wave
 /// stalls at the first instruction that needs a loaded value): `issue` does the bounds tests and starts the distance
 /// load, `finish` is the comparison.  Same result as is_state_valid.
@@ -344,8 +384,18 @@ PPD_INLINE bool is_path_valid(const MapView& m, const PathT& path, const Pose& i
 /// Same march when the validity / obstacle distance of the path's start pose is already known (firstDist < 0: the
 /// start pose is invalid): the first sample of every child arc is the parent's pose, which was checked when the parent
 /// node was created, so the march starts without waiting for a distance load.  Counts that sample like the reference.
+struct DistGlobal { };
+PPD_INLINE bool is_state_valid(const MapView& m, const DistGlobal&, double x, double y, double theta, float& distance) { return is_state_valid(m, x, y, theta, distance); }
+
+template <typename PathT, typename DistSrc>
+PPD_INLINE bool is_path_valid_from(const MapView& m, const DistSrc& src, const PathT& path, const Pose& init, float firstDist, float& last, int& checks);
 template <typename PathT>
 PPD_INLINE bool is_path_valid_from(const MapView& m, const PathT& path, const Pose& init, float firstDist, float& last, int& checks)
+{
+	return is_path_valid_from(m, DistGlobal(), path, init, firstDist, last, checks);
+}
+template <typename PathT, typename DistSrc>
+PPD_INLINE bool is_path_valid_from(const MapView& m, const DistSrc& src, const PathT& path, const Pose& init, float firstDist, float& last, int& checks)
 {
 	const double pathLength = path.length;
 	if (pathLength == 0.0) {
@@ -374,7 +424,7 @@ PPD_INLINE bool is_path_valid_from(const MapView& m, const PathT& path, const Po
 		}
 		Pose s = path.interpolate(length / pathLength);
 		checks++;
-		if (!is_state_valid(m, s.x, s.y, s.t, distance)) {
+		if (!is_state_valid(m, src, s.x, s.y, s.t, distance)) {
 			last = (float)(lastValidLength / pathLength);
 			return false;
 		}

@@ -120,6 +120,13 @@ struct DevResult {
 	int32_t nRsLog;
 };
 
+#ifndef PP_SEARCH_DIST_WINDOW
+#define PP_SEARCH_DIST_WINDOW 0 // (experiment, measured harmful) one-query kernel: LDS window of the distance grid around the expanded
+                                // node (pp_device.hpp: DistWindow), filled by LDS-DMA at the pop.  Same results; the marches' distance reads
+                                // hit L2 / MALL and were already hidden under the heuristic-field gathers (HBM misses), so the window only
+                                // adds its 18 load instructions: 25.7 k -> 29 k cycles per expansion (tools/diag_search.py, PP_SEARCH_ROWS=0)
+#endif
+
 constexpr uint32_t kExplored = 0xFFFFFFFFu;
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 
@@ -213,6 +220,9 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	__shared__ uint8_t c_valid[kSlots];
 	__shared__ int16_t c_action[kSlots];
 	__shared__ int s_rsChecks;
+#if PP_SEARCH_DIST_WINDOW
+	__shared__ __attribute__((aligned(16))) float s_win[kDistWinElems]; // obstacle distances around the expanded node (pp_device.hpp: DistWindow)
+#endif
 	__shared__ HeapEntry s_spill[16]; // entries that left the front buffer during this expansion
 	__shared__ uint8_t s_bandCnt[kBands]; // f-bands of the open list (pp_search_device.hpp): entries per ring slot
 
@@ -544,6 +554,38 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			solutionCost = pPathCost;
 			break;
 		}
+#if PP_SEARCH_DIST_WINDOW
+		// the children's marches read the distance grid within 1.5 m of this pose: fetch that window into LDS now (LDS-DMA: no
+		// registers, one round trip, lands while the heuristic and the child end points are computed)
+		DistWindow dwin;
+		{
+			int prow, pcol;
+			world_to_cell(m, ppose.x, ppose.y, prow, pcol);
+			prow = min(max(prow, 0), m.rows - 1); // (a popped node is a valid state, i.e. inside the map)
+			pcol = min(max(pcol, 0), m.cols - 1);
+			const uint32_t winLds = (uint32_t)(uintptr_t)s_win; // low half of the generic address = the LDS byte address
+			dwin.win = (LdsFloatPtr)(uintptr_t)winLds;
+			dwin.r0 = prow - kDistWinHalf;
+			dwin.c0 = pcol - kDistWinHalf;
+			// element e = k * 64 + lane of the window is cell (e / kDistWin, e % kDistWin); stepping e by 64 = one row + 31 columns
+			int wr = lane / kDistWin, wc = lane - wr * kDistWin;
+#pragma unroll 1
+			for (int k = 0; k < kDistWinElems / 64; k++) {
+				// cells beyond the map edge are never asked for (is_state_valid tests the map first): any in-range address serves
+				const int gr = min(max(dwin.r0 + wr, 0), m.rows - 1), gc = min(max(dwin.c0 + wc, 0), m.cols - 1);
+				// (the LDS address goes through an integer: the folded generic -> LDS cast of a constant address trips the gfx950 backend,
+				// "Illegal instruction: V_CMP_NE_U32 0, src_shared_base")
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(m.dist + (size_t)gr * m.cols + gc),
+					(__attribute__((address_space(3))) void*)(uintptr_t)(winLds + (uint32_t)(k * 64 * sizeof(float))), 4, 0, 0);
+				wr += 1;
+				wc += 64 - kDistWin;
+				if (wc >= kDistWin) {
+					wc -= kDistWin;
+					wr += 1;
+				}
+			}
+		}
+#endif
 		// ---- Expand, a_star.h:377-409
 		if (lane == 0) {
 			if (pKey != kNoKey)
@@ -599,7 +641,13 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				// validity / distance of the child's own pose: the first march sample of ITS children (not a counted check)
 				float cd0;
 				const bool cIn = is_state_valid_issue(m, child.x, child.y, child.t, cd0);
+#if PP_SEARCH_DIST_WINDOW
+				__builtin_amdgcn_s_waitcnt(0); // the window has landed (issued a phase ago) -- and so have the look-ups just issued
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				const bool pathValid = is_path_valid_from(m, dwin, a, a.init, pDist0, lastValidRatio, checks);
+#else
 				const bool pathValid = is_path_valid_from(m, a, a.init, pDist0, lastValidRatio, checks);
+#endif
 				PP_STAMP(PH_DUP); // [diagnostic: look-up issue + validity march]
 				// the values the look-ups above fetched (loaded under the march)
 				hh = combined_heuristic_finish(A.heur, hl);
