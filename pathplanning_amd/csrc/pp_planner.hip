@@ -120,6 +120,11 @@ struct DevResult {
 	int32_t nRsLog;
 };
 
+#ifndef PP_SEARCH_FIELD_PREFETCH
+#define PP_SEARCH_FIELD_PREFETCH 0 // (experiment, measured neutral to harmful) one-query kernel: touch the children's heuristic-field lines
+                                   // as soon as the parent pose is known.  The child phase's wait went 10.0 k -> 9.8 k cycles, the added code cost
+                                   // 1.4 k: the wait is the slowest of five independent gathers (key map, field, table, distance, path cost)
+#endif
 #ifndef PP_SEARCH_DIST_WINDOW
 #define PP_SEARCH_DIST_WINDOW 0 // (experiment, measured harmful) one-query kernel: LDS window of the distance grid around the expanded
                                 // node (pp_device.hpp: DistWindow), filled by LDS-DMA at the pop.  Same results; the marches' distance reads
@@ -544,6 +549,28 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				pDist0 = nd.dist0;
 			}
 		}
+#if PP_SEARCH_FIELD_PREFETCH
+		// The obstacle-heuristic value of a child is a gather from this query's own 4 MB field: an HBM miss every time (17 GB of
+		// fields per planner), and the child phase waits for it.  Its cell is known to within float rounding as soon as the parent
+		// pose is: touch that cache line now (fast float sin / cos: the value is discarded, only the line matters); the exact look-up
+		// two phases later finds it in L2 or on its way.
+		float prefetched = 0.0f;
+		if (lane < P) {
+			const double kap = A.prims.kappa[lane];
+			const double d = A.prims.backward[lane] ? -A.rp.arcLength : A.rp.arcLength;
+			double ax = px + d * pCos, ay = py + d * pSin;
+			if (fabs(kap) > 1e-9) {
+				const float tf = (float)(pt + d * kap);
+				const double ik = A.prims.invKappa[lane];
+				ax = px + ik * ((double)__sinf(tf) - pSin);
+				ay = py + ik * (pCos - (double)__cosf(tf));
+			}
+			int row, col;
+			world_to_cell(m, ax, ay, row, col);
+			if (inside_map(m, row, col))
+				prefetched = field[field_tiled_index(m.cols, row, col)];
+		}
+#endif
 		wave_lds_sync(); // staging is about to be overwritten
 		if (pDead)
 			continue; // entry of a node replaced by ProcessPossibleShortcut
@@ -651,6 +678,9 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				PP_STAMP(PH_DUP); // [diagnostic: look-up issue + validity march]
 				// the values the look-ups above fetched (loaded under the march)
 				hh = combined_heuristic_finish(A.heur, hl);
+#if PP_SEARCH_FIELD_PREFETCH
+				asm volatile("" : : "v"(prefetched)); // keeps the touch above alive; it arrived before the look-up it served
+#endif
 				const double voroFull = voronoi_cost_finish(voroRaw, A.rp.voroDiagRes, A.rp.voronoiMult);
 				d0 = is_state_valid_finish(m, cIn, cd0) ? cd0 : -1.0f;
 				if (!pathValid) {
