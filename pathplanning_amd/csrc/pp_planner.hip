@@ -149,8 +149,12 @@ __device__ __forceinline__ void wave_lds_sync()
 /// waits until this wave's global stores are visible to its other lanes' loads
 __device__ __forceinline__ void wave_vmem_sync()
 {
+#if PP_WAVE_SYNC_DRAIN
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	__builtin_amdgcn_s_waitcnt(0);
+#else
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
 	__builtin_amdgcn_wave_barrier();
 }
 
@@ -446,8 +450,12 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			const int cntSl = s_bandCnt[sl];
 			const bool mineBand = cntSl > 0 && bn >= bandLo && bn < bandLo + kBands;
 			const bool have = mineBand && (lane & 15) < cntSl;
+#if PP_WAVE_SYNC_DRAIN
 			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 			__builtin_amdgcn_s_waitcnt(0); // lane 0's band stores
+#else
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
 			HeapEntry e;
 			e.ckey = ~0ull;
 			e.nseq = ~0u;

@@ -6,11 +6,18 @@
 
 namespace ppd {
 
-/// waits until this wave's global stores are visible to its other lanes' loads
+#ifndef PP_WAVE_SYNC_DRAIN
+#define PP_WAVE_SYNC_DRAIN 1 // 0 (experiment): rely on the in-order execution of one wave's memory instructions instead of draining its stores
+#endif
+/// this wave's global stores are visible to its other lanes' loads
 PPD_INLINE void row_vmem_sync()
 {
+#if PP_WAVE_SYNC_DRAIN
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	__builtin_amdgcn_s_waitcnt(0);
+#else
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
 	__builtin_amdgcn_wave_barrier();
 }
 
