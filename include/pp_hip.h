@@ -93,9 +93,21 @@ int pp_rasterize_cells(pp_map* map, int32_t n_segments, const double* p0_xy_host
 int pp_map_set_cells(pp_map* map, int64_t n_cells, const int32_t* cells_host, int32_t value);
 int pp_map_download_occupancy(pp_map* map, int32_t* occ_host);
 /* GVD::Update (state_validator/gvd.cpp:294-301) from the device occupancy grid: squared obstacle distance + nearest obstacle cell
- * (gvd.cpp:30-72), Voronoi edges (:105-131), squared distance to the nearest edge (:200-237), PathCostMap (:266-283; alpha,
- * d_max: GVD::alpha / dMax, gvd.h:181); also refreshes what the validator reads.  The distance maps are the fixed point of the
- * same 8-neighbour label propagation as the reference's brushfire, not its heap order: see pp_gvd.hip for what that means. */
+ * (ObstacleDistanceMap::Update, gvd.cpp:30-72), Voronoi edges (CheckVoro, :105-131), squared distance to the nearest edge
+ * (VoronoiDistanceMap::Update, :200-237), PathCostMap (:266-283; alpha, d_max: GVD::alpha / dMax, gvd.h:181); also refreshes what
+ * the validator reads.  Two modes for the two distance maps:
+ *   PP_GVD_REFERENCE_ORDER  the reference's dynamic brushfire itself, replayed (on the host: it is a sequential priority-queue sweep
+ *                           whose order among equal keys is part of the result) over the ORDERED cell edits this map has received
+ *                           -- pp_map_set_cells / pp_map_rasterize_segments in call order, cells in list order, i.e.
+ *                           SetObstacle / UnsetObstacle (gvd.cpp:74-89) as AddObstacle / RemoveObstacle issue them; a
+ *                           pp_map_upload_occupancy counts as an empty map followed by its occupied cells in row-major order.
+ *                           Grids equal the reference's bit for bit; edits after the first update are incremental.
+ *   PP_GVD_EXACT_EDT        exact Euclidean transform on the device (milliseconds, no host round trip): true minima, which the
+ *                           brushfire's values are not always, and its own tie rule -- NOT the reference's bits on a few cells in
+ *                           ten thousand.  pp_map_update_gvd = this mode.
+ * iterations_out (may be NULL): heap pops of the brushfire so far / device passes. */
+enum { PP_GVD_EXACT_EDT = 0, PP_GVD_REFERENCE_ORDER = 1 };
+int pp_map_update_gvd_ex(pp_map* map, float alpha, float d_max, int32_t mode, int32_t* iterations_out);
 int pp_map_update_gvd(pp_map* map, float alpha, float d_max, int32_t* iterations_out);
 /* any pointer may be NULL; nearest_*: (row, col) per cell, (-1, -1) = none */
 int pp_map_download_gvd(pp_map* map, int32_t* d2_host, int32_t* nearest_obstacle_host, uint8_t* voronoi_edge_host, int32_t* voronoi_d2_host, int32_t* nearest_edge_host,

@@ -386,6 +386,9 @@ void ppo_se2_paths_valid(void* wv, int64_t n, const double* from, const double* 
 	}
 }
 
+/// sensitivity probe of the smoother's curvature term (ppo_post.hpp: Smoother::LibmLastBit)
+void ppo_smoother_libm_last_bit(int shift) { Smoother::LibmLastBit() = shift; }
+
 // --------------------------------------------- post-processing + smoother ----
 struct PostHandle {
 	std::vector<Pose2d> resampled, smoothed;

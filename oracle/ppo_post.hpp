@@ -156,12 +156,26 @@ struct Smoother {
 				return false;
 		return true;
 	}
+	/// 0: the restatement as it is.  +1 / -1: every cosine of the curvature term is moved one ulp up / down -- what another libm
+	/// build (glibc selects FMA or SSE2 variants of cos per CPU) may legitimately return.  A query whose smoothed path moves by
+	/// more than the parity tolerance under this probe has no machine-independent reference result.
+	static int& LibmLastBit()
+	{
+		static int v = 0;
+		return v;
+	}
 	void CurvatureTerm(const V2& xim1, const V2& xi, const V2& xip1, V2& gim1, V2& gi, V2& gip1) const
 	{
 		// smoother.cpp:160-214
 		V2 deltaXi { xi.x - xim1.x, xi.y - xim1.y };
 		V2 deltaXip1 { xip1.x - xi.x, xip1.y - xi.y };
-		float deltaPhi = std::acos(std::clamp<float>((deltaXi.normalized().dot(deltaXip1.normalized())), -1.0f, 1.0f));
+		// The reference writes UNQUALIFIED acos / cos / sqrt on floats here.  Its translation unit sees <cmath> (through Eigen) but
+		// neither <math.h> nor a using-directive, so only the C library's ::acos(double), ::cos(double), ::sqrt(double) are
+		// visible unqualified (std::acos(float) is not; no ADL for a fundamental type): the float argument is promoted, the
+		// function runs in DOUBLE and the result is narrowed on assignment.  (Checked with g++ 11 on a probe that includes what
+		// Eigen/Core includes: decltype(acos(1.0f)) is double.)  So 1 - cos^2 below is formed in double -- no cancellation at
+		// float level.  Rounds 1-2 restated these as std::acos / std::cos (the float overloads), which was wrong.
+		float deltaPhi = ::acos((double)std::clamp<float>((deltaXi.normalized().dot(deltaXip1.normalized())), -1.0f, 1.0f));
 		float kappa = deltaPhi / deltaXi.norm();
 		if (kappa <= p.maxCurvature)
 			return;
@@ -169,7 +183,10 @@ struct Smoother {
 		V2 oc1 = OrthogonalComplement(deltaXip1, deltaXi), oc2 = OrthogonalComplement(deltaXi, deltaXip1);
 		V2 DcosDeltaPhi_DdeltaXi { oc1.x / denominator, oc1.y / denominator };
 		V2 DcosDeltaPhi_DdeltaXip1 { oc2.x / denominator, oc2.y / denominator };
-		float DdeltaPhi_DcosDeltaPhi = -1.0f / std::sqrt(1.0f - std::pow(std::cos(deltaPhi), 2));
+		double cosDeltaPhi = ::cos((double)deltaPhi);
+		if (LibmLastBit() != 0) // sensitivity probe (tests only): the cosine moved by one unit in the last place
+			cosDeltaPhi = std::nextafter(cosDeltaPhi, LibmLastBit() > 0 ? 2.0 : -2.0);
+		float DdeltaPhi_DcosDeltaPhi = -1.0f / ::sqrt(1.0f - std::pow(cosDeltaPhi, 2));
 		float coef1 = 1 / deltaXi.norm() * DdeltaPhi_DcosDeltaPhi;
 		V2 nrm = deltaXi.normalized();
 		double c2 = deltaPhi / deltaXi.squaredNorm();

@@ -5,7 +5,8 @@
 // Built by oracle/Makefile from the sources where they lie under
 // /root/reference (never copied), into oracle/_ref/libppref.so, and used by
 // tests/test_oracle_ref.py to pin the oracle's open-list pop order (Appendix
-// A Q1), neighbour enumeration (Q4) and uniform sampling (Q9) to the
+// A Q1), neighbour enumeration (Q4), uniform sampling (Q9) and the SE(2) state-space
+// samplers (uniform + Gaussian, state_space_se2.cpp:27-52) to the
 // reference's own code.  Compiled with -fno-access-control so the driver can
 // reseed Random<double>::s_engine (private static).
 #include <algorithm>
@@ -90,6 +91,22 @@ void ref_rng_uniform(unsigned long long seed, long long n, double lb, double ub,
 	Planner::Random<double>::s_uniformDistribution.reset();
 	for (long long i = 0; i < n; i++)
 		out[i] = Planner::Random<double>::SampleUniform(lb, ub);
+}
+
+/// n draws of StateSpaceSE2::SampleUniform's pattern (state_space_se2.cpp:27-38: x, y, theta from Random<double>::SampleUniform) followed
+/// by n draws of SampleGaussian's (:40-52, before EnforceBounds), all from the reference's own utils/random.h
+void ref_rng_se2(unsigned long long seed, long long n, const double* lb, const double* ub, const double* mean, const double* stdDev, double* uniformOut, double* gaussOut)
+{
+	Planner::Random<double>::Init();
+	Planner::Random<double>::s_engine->seed(seed);
+	Planner::Random<double>::s_uniformDistribution.reset();
+	Planner::Random<double>::s_gaussianDistribution.reset();
+	for (long long i = 0; i < n; i++)
+		for (int k = 0; k < 3; k++)
+			uniformOut[3 * i + k] = Planner::Random<double>::SampleUniform(lb[k], ub[k]);
+	for (long long i = 0; i < n; i++)
+		for (int k = 0; k < 3; k++)
+			gaussOut[3 * i + k] = Planner::Random<double>::SampleGaussian(mean[k], stdDev[k]);
 }
 
 double ref_modulo(double a, double b) { return Planner::Maths::Modulo(a, b); }

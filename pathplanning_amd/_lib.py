@@ -121,6 +121,7 @@ def load():
     L.pp_map_rasterize_segments.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
     L.pp_map_download_occupancy.argtypes = [vp, vp]
     L.pp_map_update_gvd.argtypes = [vp, C.c_float, C.c_float, vp]
+    L.pp_map_update_gvd_ex.argtypes = [vp, C.c_float, C.c_float, C.c_int32, vp]
     L.pp_map_download_gvd.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.pp_path_cost_update.argtypes = [vp, vp, vp, C.c_float, C.c_float, vp]
     L.pp_rs_connect.argtypes = [vp, C.c_int64, vp, vp, C.c_double, C.c_float, C.c_float, C.c_float, vp]

@@ -112,6 +112,7 @@ void map_release(pp_map* map)
 	for (void* q : more)
 		if (q)
 			(void)hipFree(q);
+	gvd_reference_free(map);
 	pp_ctx* ctx = map->ctx;
 	delete map;
 	ctx_release(ctx);
@@ -274,6 +275,16 @@ int pp_map_upload_occupancy(pp_map* map, const int32_t* occ_host)
 	if (!map->occ8)
 		PP_HIP_TRY(hipMalloc((void**)&map->occ8, n));
 	PP_HIP_TRY(hipMemcpyAsync(map->occ32, occ_host, n * sizeof(int32_t), hipMemcpyHostToDevice, map->ctx->stream));
+	// for the reference-order field update (pp_map_update_gvd_ex) a whole-grid upload is "an empty map, then every occupied cell in
+	// row-major order": the reference has no such entry point (its cells only arrive through AddObstacle), so this order is ours
+	map->journal.clear();
+	map->journalLost = false;
+	map->journalReset = true;
+	for (size_t i = 0; i < n; i++)
+		if (occ_host[i] >= 0) {
+			map->journal.push_back((int32_t)i);
+			map->journal.push_back(occ_host[i]);
+		}
 	PP_HIP_TRY(launch_occ_to_u8(map->ctx->stream, map->occ32, map->occ8, (int64_t)n));
 	PP_HIP_TRY(hipStreamSynchronize(map->ctx->stream));
 	return PP_OK;

@@ -89,6 +89,8 @@ hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, co
 struct pp_ctx;
 struct pp_map;
 namespace pph {
+struct GvdReference;
+void gvd_reference_free(pp_map* map); // pp_gvd.hip
 void ctx_release(pp_ctx* ctx); // drops one reference, frees at zero
 void map_release(pp_map* map);
 } // namespace pph
@@ -122,6 +124,12 @@ struct pp_map {
 	int32_t* voroD2 = nullptr;
 	uint8_t* voroEdge = nullptr;
 	int32_t* gvdFlag = nullptr;
+	// reference-order field construction (pp_brushfire_host.hpp): the host brushfire's persistent state and the ordered cell
+	// edits (cell, value pairs) made since it last ran.  journalReset: the grid was replaced as a whole before the recorded
+	// edits (pp_map_upload_occupancy); journalLost: edits were dropped, the next run re-seeds from the device grid.
+	pph::GvdReference* gvdRef = nullptr;
+	std::vector<int32_t> journal;
+	bool journalReset = false, journalLost = false;
 	ppd::MapView view() const;
 	size_t cells() const { return (size_t)desc.rows * desc.cols; }
 };

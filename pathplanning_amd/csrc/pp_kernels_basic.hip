@@ -8,6 +8,8 @@
 //   knn               a14 exact k nearest neighbours (flann replacement)
 #include "pp_internal.hpp"
 
+#include <mutex>
+
 #include <cstdlib>
 #include "pp_rs_device.hpp"
 
@@ -447,17 +449,25 @@ hipError_t launch_check_states(hipStream_t s, const MapView& m, int64_t n, const
 	static const int ldsMode = getenv("PP_CS_LDS") ? atoi(getenv("PP_CS_LDS")) : 1; // measurement switch: 0 = never use the LDS-resident bitmap
 	if (!staged && ldsMode && (((uintptr_t)poses) & 15) == 0 && (((uintptr_t)valid) & 3) == 0 && bitmapWords * 4 <= 128 * 1024 && bitmapWords % 4 == 0 && n >= (1 << 20)) {
 		const size_t ldsBytes = (size_t)bitmapWords * 4 + (size_t)kLdsTile * 24 + 2 * kLdsTile;
-		static bool attrSet = false;
-		if (!attrSet) { // more than 64 KiB of LDS per workgroup has to be asked for once
-			hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_check_states_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-			if (e != hipSuccess)
-				return e;
-			attrSet = true;
+		// more than 64 KiB of LDS per workgroup has to be asked for, once PER DEVICE (the attribute belongs to the function on a
+		// device): a flag and the CU count per device id, set under a lock
+		int dev = 0;
+		(void)hipGetDevice(&dev);
+		static std::mutex attrLock;
+		static int cusOf[64] = {}; // 0: attribute not yet set on that device
+		int cus = 0;
+		{
+			std::lock_guard<std::mutex> g(attrLock);
+			const int slot = dev >= 0 && dev < 64 ? dev : 63;
+			if (!cusOf[slot] || slot == 63) {
+				hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_check_states_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+				if (e != hipSuccess)
+					return e;
+				hipDeviceProp_t prop;
+				cusOf[slot] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+			}
+			cus = cusOf[slot];
 		}
-		int dev = 0, cus = 256;
-		hipDeviceProp_t prop;
-		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-			cus = prop.multiProcessorCount;
 		const int64_t tiles = n / kLdsTile;
 		hipLaunchKernelGGL(k_check_states_lds, dim3((unsigned)(tiles < cus ? tiles : cus)), dim3(kLdsBlock), ldsBytes, s, m, tiles, reinterpret_cast<const dvec2*>(poses),
 			reinterpret_cast<uint32_t*>(valid), bitmapWords);

@@ -1799,6 +1799,7 @@ int pp_planner_postprocess(pp_planner* planner, int32_t n_queries, float path_in
 	const size_t B = (size_t)planner->maxBatch;
 	if (planner->postMaxPoints < max_points) {
 		void* old[] = { planner->post.ratios, planner->post.resampled, planner->post.smoothed, planner->post.cusp, planner->post.optimise };
+		planner->postMaxPoints = 0; // until every buffer below exists again: a failed allocation must not leave a stale capacity behind
 		for (void* q : old)
 			if (q)
 				(void)hipFree(q);

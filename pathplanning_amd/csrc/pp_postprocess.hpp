@@ -58,9 +58,10 @@ __device__ __forceinline__ bool curvature_term(const PostParams& P, V2d xim1, V2
 	const V2d deltaXi = { xi.x - xim1.x, xi.y - xim1.y }, deltaXip1 = { xip1.x - xi.x, xip1.y - xi.y };
 	float c = (float)v2_dot(v2_normalized(deltaXi), v2_normalized(deltaXip1));
 	c = c < -1.0f ? -1.0f : (1.0f < c ? 1.0f : c); // std::clamp<float>: a NaN passes through
-	// float acos / cos evaluated in double and rounded once: the correctly rounded float result (up to double's own last bit),
-	// which is what a good libm returns.  It matters: 1 - cos^2 below cancels almost everything for small angles, so a
-	// one-ulp difference in cosf shows up as 1e-4 .. 1e-3 relative in the curvature gradient.
+	// smoother.cpp:164,200 call acos / cos / sqrt UNQUALIFIED on floats: with <cmath> alone (no <math.h>, no using-directive) these
+	// are the C library's double functions -- the argument is promoted, the result narrowed on assignment.  So acos runs in
+	// double and is stored as float, and 1 - cos^2 is formed in DOUBLE from the double cosine of that float (no float rounding
+	// of the cosine in between: rounds 1-2 had one, which made the cancellation below 1e-4 .. 1e-3 relative).
 	const float deltaPhi = (float)acos((double)c);
 	const float kappa = (float)((double)deltaPhi / v2_norm(deltaXi));
 	if (kappa <= P.maxCurvature)
@@ -68,7 +69,7 @@ __device__ __forceinline__ bool curvature_term(const PostParams& P, V2d xim1, V2
 	const float denominator = (float)(v2_norm(deltaXi) * v2_norm(deltaXip1));
 	const V2d oc1 = orthogonal_complement(deltaXip1, deltaXi), oc2 = orthogonal_complement(deltaXi, deltaXip1);
 	const V2d dA = { oc1.x / (double)denominator, oc1.y / (double)denominator }, dB = { oc2.x / (double)denominator, oc2.y / (double)denominator };
-	const double cs = (double)(float)cos((double)deltaPhi);
+	const double cs = cos((double)deltaPhi);
 	const float DdeltaPhi = (float)((double)-1.0f / sqrt((double)1.0f - cs * cs));
 	const float coef1 = (float)(1 / v2_norm(deltaXi) * (double)DdeltaPhi);
 	const V2d nrm = v2_normalized(deltaXi);

@@ -197,13 +197,15 @@ private:
 	std::set<unsigned int> m_ids;
 };
 
-/// state_validator/gvd.{h,cpp}: the three fields over an occupancy map, built on the device (see pp_gvd.hip for how the
-/// distance maps relate to the reference's brushfire)
+/// state_validator/gvd.{h,cpp}: the three fields over an occupancy map.  By default the two distance maps are the reference's own
+/// brushfire (OccupancyMap::FieldUpdateMode::ReferenceOrder: bit-identical grids); SetUpdateMode(ExactTransform) opts into the
+/// device's exact Euclidean transform (see pp_gvd.hip for how the two relate)
 class GVD {
 public:
 	explicit GVD(const Ref<OccupancyMap>& map) : rows(map->Rows()), columns(map->Columns()), resolution(map->resolution), m_map(map) { }
 	/// gvd.cpp:294-301
 	void Update() { m_map->BuildFields(alpha, dMax); }
+	void SetUpdateMode(OccupancyMap::FieldUpdateMode mode) { m_map->SetFieldUpdateMode(mode); }
 	GridCellPosition GetNearestObstacleCell(int row, int col) const { return Cell(m_map->Voronoi().nearestObstacle, row, col); }
 	GridCellPosition GetNearestObstacleCell(const GridCellPosition& c) const { return GetNearestObstacleCell(c.row, c.col); }
 	GridCellPosition GetNearestVoronoiEdgeCell(int row, int col) const { return Cell(m_map->Voronoi().nearestEdge, row, col); }

@@ -12,6 +12,8 @@
 // Everything computes on the GPU; constructing any of the HIP-backed classes without a device throws.
 #pragma once
 
+#include <random>
+#include <limits>
 #include <cstdio>
 
 #include "types.hpp"
@@ -40,6 +42,56 @@ using PathPlannerR2Base = PathPlanner<Point2d>;
 using PathPlannerSE2Base = PathPlanner<Pose2d>;
 
 /// state_space/state_space_se2.{h,cpp}
+/// utils/random.h:9-44: the process-wide std::mt19937_64 with a uniform [0, 1] and a standard normal distribution.  Same
+/// standard-library objects as the reference, so the same seed gives the same stream.  (The searches do not draw from it: every
+/// query carries its own engine on the device.)  Seed() is not in the reference, which seeds from std::random_device only.
+template <typename T>
+class Random {
+public:
+	static void Init()
+	{
+		if (!State().ready) {
+			State().engine.seed(std::random_device {}());
+			Reset();
+		}
+	}
+	static void Seed(unsigned long long seed)
+	{
+		State().engine.seed(seed);
+		Reset();
+	}
+	static T SampleUniform(T lb, T ub)
+	{
+		Init();
+		const T range = ub - lb;
+		return lb + range * State().uniform(State().engine);
+	}
+	static T SampleGaussian(const T& mean, const T& stdDev)
+	{
+		Init();
+		return mean + stdDev * State().gaussian(State().engine);
+	}
+
+private:
+	struct S {
+		std::mt19937_64 engine;
+		std::uniform_real_distribution<T> uniform;
+		std::normal_distribution<T> gaussian;
+		bool ready = false;
+	};
+	static S& State()
+	{
+		static S s;
+		return s;
+	}
+	static void Reset()
+	{
+		State().uniform = std::uniform_real_distribution<T>(0.0, std::nextafter(1.0, std::numeric_limits<T>::max()));
+		State().gaussian = std::normal_distribution<T>(0.0, 1.0);
+		State().ready = true;
+	}
+};
+
 class StateSpaceSE2 {
 public:
 	explicit StateSpaceSE2(const std::array<Pose2d, 2>& b) : bounds(b) { }
@@ -56,6 +108,24 @@ public:
 		if (s.y() < bounds[0].y() || s.y() > bounds[1].y()) return false;
 		if (s.theta < bounds[0].theta || s.theta > bounds[1].theta) return false;
 		return true;
+	}
+	/// state_space_se2.cpp:27-52: x, y, theta drawn in this order from the global engine; the Gaussian sample is clamped to the bounds
+	Pose2d SampleUniform() const
+	{
+		Pose2d s;
+		s.x() = Random<double>::SampleUniform(bounds[0].x(), bounds[1].x());
+		s.y() = Random<double>::SampleUniform(bounds[0].y(), bounds[1].y());
+		s.theta = Random<double>::SampleUniform(bounds[0].theta, bounds[1].theta);
+		return s;
+	}
+	Pose2d SampleGaussian(const Pose2d& mean, const Pose2d& stdDev) const
+	{
+		Pose2d s;
+		s.x() = Random<double>::SampleGaussian(mean.x(), stdDev.x());
+		s.y() = Random<double>::SampleGaussian(mean.y(), stdDev.y());
+		s.theta = Random<double>::SampleGaussian(mean.theta, stdDev.theta);
+		EnforceBounds(s);
+		return s;
 	}
 	const std::array<Pose2d, 2> bounds;
 };
@@ -225,11 +295,18 @@ public:
 		}
 		return m_dev;
 	}
-	/// GVD::Update (gvd.cpp:294-301) on the device, from the device occupancy grid
+	/// How GVD::Update builds its two distance maps (pp_map_update_gvd_ex).  ReferenceOrder (the default of this drop-in): the
+	/// reference's own brushfire, its grids bit for bit, incremental after the first build.  ExactTransform: the exact Euclidean
+	/// transform on the device, milliseconds instead of seconds, NOT the reference's bits on a few tie cells in ten thousand --
+	/// an opt-in for callers that rebuild large maps often.
+	enum class FieldUpdateMode { ReferenceOrder = PP_GVD_REFERENCE_ORDER, ExactTransform = PP_GVD_EXACT_EDT };
+	void SetFieldUpdateMode(FieldUpdateMode mode) { m_fieldMode = mode; }
+	FieldUpdateMode GetFieldUpdateMode() const { return m_fieldMode; }
+	/// GVD::Update (gvd.cpp:294-301) from the device occupancy grid
 	void BuildFields(float alpha, float dMax)
 	{
 		pp_map* d = Device(); // (pushes a host-set occupancy first)
-		ppCheck(pp_map_update_gvd(d, alpha, dMax, nullptr));
+		ppCheck(pp_map_update_gvd_ex(d, alpha, dMax, (int32_t)m_fieldMode, nullptr));
 		m_onDevice = true;
 		m_hostStale = true;
 		m_fieldsBuilt = true;
@@ -300,6 +377,7 @@ protected:
 	pp_map* m_dev = nullptr;
 	uint64_t m_hostVersion = 0, m_uploaded = ~0ull;
 	bool m_onDevice = false, m_hostStale = false, m_fieldsBuilt = false, m_nearestOnHost = false;
+	FieldUpdateMode m_fieldMode = FieldUpdateMode::ReferenceOrder;
 };
 
 /// state_validator/state_validator.h:10-43 (SE2 instantiation)
@@ -585,7 +663,12 @@ public:
 				m_smootherParam.smoothWeight, m_smootherParam.voronoiWeight, m_smootherParam.collisionWeight, m_smootherParam.curvatureWeight, m_smootherParam.collisionRatio,
 				m_smootherParam.maxCurvature };
 			pp_post_result post {};
-			if (pp_planner_postprocess(m_planner, 1, pathInterpolation, &sp, 2048, &post) == 0 && post.n_points > 0) {
+			const int postRc = pp_planner_postprocess(m_planner, 1, pathInterpolation, &sp, 2048, &post);
+			m_postOverflow = postRc == 0 && post.smoothing_status == -4;
+			if (m_postOverflow) // more samples than the device post-processing holds (2048): said, not hidden -- GetPath() keeps the graph-search nodes
+				std::fprintf(stderr, "[pathplanning_amd] HybridAStar::SearchPath: the path (%.1f m at %.3f m spacing) has more than 2048 samples; it was neither "
+					"sampled nor smoothed, GetPath() returns the graph-search nodes (raise pathInterpolation)\n", post.length, (double)pathInterpolation);
+			if (postRc == 0 && post.n_points > 0) {
 				std::vector<Pose2d> sampled((size_t)post.n_points), smoothed((size_t)post.n_points);
 				ppCheck(pp_planner_get_processed_path(m_planner, 0, &sampled[0].position.v[0], nullptr, &smoothed[0].position.v[0]));
 				m_stats.smoothingStatus = (Smoother::Status)post.smoothing_status;
@@ -597,6 +680,8 @@ public:
 	}
 	/// algo/hybrid_a_star.h:226: the sampled, and when the smoother succeeds smoothed, path (see SearchPath)
 	std::vector<Pose2d> GetPath() const override { return m_path; }
+	/// the last SearchPath's path had more samples than the device post-processing holds: GetPath() is the graph-search nodes
+	bool PostProcessingOverflowed() const { return m_postOverflow; }
 	/// algo/hybrid_a_star.h:237: what the smoother ended with (also when it failed)
 	const std::vector<Pose2d>& GetSmoothedPath() const { return m_smoothed; }
 	const Smoother::Parameters& GetSmootherParameters() const { return m_smootherParam; }
@@ -735,6 +820,7 @@ private:
 	pp_query_result m_last {};
 	Smoother::Parameters m_smootherParam;
 	std::vector<Pose2d> m_path, m_smoothed;
+	bool m_postOverflow = false;
 	Stats m_stats;
 	uint64_t m_seed = 0;
 };

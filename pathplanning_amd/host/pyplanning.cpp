@@ -115,7 +115,11 @@ PYBIND11_MODULE(pyplanning, m)
 		.def(py::init<const Pose2d&, const Pose2d&>())
 		.def("enforce_bounds", &StateSpaceSE2::EnforceBounds)
 		.def("validate_bounds", &StateSpaceSE2::ValidateBounds)
+		.def("sample_uniform", &StateSpaceSE2::SampleUniform)   // pyplanning.cpp:325
+		.def("sample_gaussian", &StateSpaceSE2::SampleGaussian) // pyplanning.cpp:326
 		.def_readonly("bounds", &StateSpaceSE2::bounds);
+	// not in the reference (its engine is seeded from std::random_device only): a fixed seed for the global engine the two samplers draw from
+	m.def("seed_random", [](unsigned long long seed) { Random<double>::Seed(seed); });
 
 	struct OccupancyMapWrapper : OccupancyMap { // pyplanning.cpp:337-341: Python may subclass the map
 		using OccupancyMap::OccupancyMap;
@@ -130,6 +134,12 @@ PYBIND11_MODULE(pyplanning, m)
 		.def("get_position", &OccupancyMap::GetPosition)
 		.def("update", &OccupancyMap::Update)
 		.def("is_occupied", &OccupancyMap::IsOccupied)
+		.def("is_occupied)", &OccupancyMap::IsOccupied) // the name the reference actually registers (pyplanning.cpp:351, a typo): reachable by getattr only
+		// bound by the reference (pyplanning.cpp:354) although GVD::ObstacleDistanceMap is not a bound class: calling it there raises
+		// TypeError ("Unable to convert function return value to a Python type"); the same here
+		.def("get_obstacle_map", [](OccupancyMap&) -> py::object {
+			throw py::type_error("Unable to convert function return value to a Python type! The signature was\n\t(self: pyplanning.OccupancyMap) -> GVD::ObstacleDistanceMap");
+		})
 		.def("get_occupancy_value", py::overload_cast<int, int>(&OccupancyMap::GetOccupancyValue))
 		.def("get_occupancy_value", py::overload_cast<const GridCellPosition&>(&OccupancyMap::GetOccupancyValue))
 		.def("grid_cell_to_local_position", &OccupancyMap::GridCellToLocalPosition)
@@ -215,6 +225,16 @@ PYBIND11_MODULE(pyplanning, m)
 	py::class_<GVD>(m, "GVD")
 		.def(py::init<const Ref<OccupancyMap>&>())
 		.def("update", &GVD::Update)
+		// not in the reference's module: how Update builds the two distance maps ("reference_order", the default: the reference's
+		// brushfire bit for bit; "exact_transform": the device's exact Euclidean transform, see pp_hip.h: pp_map_update_gvd_ex)
+		.def("set_update_mode", [](GVD& g, const std::string& mode) {
+			if (mode == "reference_order")
+				g.SetUpdateMode(OccupancyMap::FieldUpdateMode::ReferenceOrder);
+			else if (mode == "exact_transform")
+				g.SetUpdateMode(OccupancyMap::FieldUpdateMode::ExactTransform);
+			else
+				throw std::invalid_argument("mode: 'reference_order' or 'exact_transform'");
+		})
 		.def("get_distance_to_nearest_obstacle", py::overload_cast<int, int>(&GVD::GetDistanceToNearestObstacle, py::const_))
 		.def("get_distance_to_nearest_obstacle", py::overload_cast<const GridCellPosition&>(&GVD::GetDistanceToNearestObstacle, py::const_))
 		.def("get_distance_to_nearest_voronoi_edge", py::overload_cast<int, int>(&GVD::GetDistanceToNearestVoronoiEdge, py::const_))

@@ -144,10 +144,14 @@ class OccupancyMapSet:
         check(self.lib.pp_map_download_occupancy(self.h, ptr(occ)))
         return occ
 
-    def update_gvd(self, alpha=20.0, d_max=30.0):
-        """GVD::Update on the device from the device occupancy grid; returns the number of propagation steps."""
+    GVD_EXACT_EDT, GVD_REFERENCE_ORDER = 0, 1
+
+    def update_gvd(self, alpha=20.0, d_max=30.0, mode=0):
+        """GVD::Update from the device occupancy grid.  mode GVD_REFERENCE_ORDER: the reference's brushfire replayed over the ordered cell
+        edits (grids bit-identical to the reference's, incremental after the first call; returns heap pops so far); GVD_EXACT_EDT
+        (default): exact Euclidean transform on the device (returns the number of device passes)."""
         it = C.c_int32(0)
-        check(self.lib.pp_map_update_gvd(self.h, C.c_float(alpha), C.c_float(d_max), C.byref(it)))
+        check(self.lib.pp_map_update_gvd_ex(self.h, C.c_float(alpha), C.c_float(d_max), int(mode), C.byref(it)))
         return it.value
 
     def download_gvd(self):

@@ -111,6 +111,10 @@ class World:
     def add_rectangle(self, dx, dy, pose):
         return lib().ppo_world_add_rectangle(self.h, C.c_double(dx), C.c_double(dy), dptr(arr3(pose)))
 
+    def remove_rectangle(self, ident, dx, dy, pose):
+        """ObstacleListOccupancyMap::RemoveObstacle (obstacle_list_occupancy_map.cpp:46-61) of a rectangle added with add_rectangle"""
+        return lib().ppo_world_remove_rectangle(self.h, C.c_int(int(ident)), C.c_double(dx), C.c_double(dy), dptr(arr3(pose)))
+
     def add_circle(self, radius, count, pose):
         return lib().ppo_world_add_circle(self.h, C.c_double(radius), C.c_int(count), dptr(arr3(pose)))
 
@@ -430,6 +434,11 @@ def postprocess(world, result, goal, params=None, path_interpolation=0.1, smooth
     L.ppo_post_get(h, dptr(resampled), u8ptr(cusp), dptr(smoothed), dptr(ratios))
     L.ppo_post_destroy(h)
     return dict(n_points=k, status=status.value, iterations=iters.value, length=plen.value, resampled=resampled, cusp=cusp.astype(bool), smoothed=smoothed, ratios=ratios)
+
+
+def smoother_libm_last_bit(shift):
+    """Sensitivity probe (ppo_post.hpp: Smoother::LibmLastBit): +1 / -1 moves every cosine of the curvature term one ulp, 0 restores."""
+    lib().ppo_smoother_libm_last_bit(C.c_int(int(shift)))
 
 
 def world_nearest(world):

@@ -1,8 +1,9 @@
 """-m gpu: map authoring and field construction on the device against the oracle's restatement of
 state_validator/obstacle.cpp, obstacle_list_occupancy_map.cpp and gvd.cpp (the reference's dynamic brushfire with the same
-libstdc++ priority queue).  Exact: outline rasterisation, PathCostMap::Update.  Bounded: the two distance maps -- the device
-computes the fixed point of the brushfire's own 8-neighbour label propagation (= the exact EDT on these maps), the brushfire's
-heap order leaves a few tie cells short of it; Voronoi edges follow CheckVoro on final labels."""
+libstdc++ priority queue).  Exact: outline rasterisation, PathCostMap::Update, and -- in the reference-order mode of
+pp_map_update_gvd_ex -- every grid of GVD::Update (d2, nearest obstacle cell, Voronoi edges, Voronoi d2, nearest edge cell, path
+cost), also after incremental AddObstacle / RemoveObstacle.  The throughput mode (exact Euclidean transform on the device) is
+compared with scipy's EDT (equal) and with the brushfire (bounded: the brushfire over-estimates a few tie cells)."""
 import json
 import math
 import os
@@ -75,6 +76,73 @@ def test_path_cost_update_is_bit_exact():
         assert (want > 0).mean() > 0.5
 
 
+def assert_fields_equal_the_brushfire(ms, w, where):
+    g = ms.download_gvd()
+    no, ne = O.world_nearest(w)
+    assert np.array_equal(g["d2"], w.d2()), where
+    assert np.array_equal(g["nearest_obstacle"], no), where
+    assert np.array_equal(g["voronoi_d2"], w.voro_d2()), where
+    assert np.array_equal(g["nearest_edge"], ne), where
+    assert np.array_equal(g["voronoi_edge"].astype(bool), w.voro_d2() == 0), where
+    assert np.array_equal(g["path_cost"].view(np.uint32), w.pathcost().view(np.uint32)), where
+    return g
+
+
+@pytest.mark.parametrize("cells,n,seed", [(256, 6, 3), (512, 12, 1), (1024, 24, 1)])
+def test_reference_order_mode_equals_the_brushfire_bit_for_bit(cells, n, seed):
+    """SURVEY 8f rank 1 ('needs a parity mode vs Lau brushfire'): PP_GVD_REFERENCE_ORDER returns the reference's grids exactly --
+    the same std::priority_queue over the same sequence of SetObstacle calls (gvd.cpp:30-89, 105-131, 200-255)."""
+    w, ms, ctx = build_pair(cells, seeded_shapes(cells, n, seed))
+    w.update()
+    pops = ms.update_gvd(mode=ms.GVD_REFERENCE_ORDER)
+    g = assert_fields_equal_the_brushfire(ms, w, "first build")
+    assert pops > cells * cells and (g["voronoi_edge"] != 0).sum() > cells
+    # the validator reads the freshly built grids
+    import pathplanning_amd as pa
+    val = pa.StateValidatorOccupancyMap(ms)
+    rng = np.random.RandomState(1)
+    half = float(w.ub[0])
+    poses = np.column_stack([rng.uniform(-half, half, 20000), rng.uniform(-half, half, 20000), rng.uniform(-3.1, 3.1, 20000)])
+    assert np.array_equal(val.is_state_valid(poses), w.is_state_valid(poses).astype(bool))
+
+
+def test_reference_order_mode_incremental_add_and_remove():
+    """gvd.cpp:74-89: SetObstacle / UnsetObstacle after the first build run the brushfire's raise and lower waves from the state the
+    previous Update left -- both sides keep that state, so the grids stay identical through a sequence of edits, and an edit
+    costs far fewer heap pops than the first build."""
+    cells = 512
+    shapes = seeded_shapes(cells, 10, 7)
+    w, ms, ctx = build_pair(cells, shapes)
+    w.update()
+    first = ms.update_gvd(mode=ms.GVD_REFERENCE_ORDER)
+    assert_fields_equal_the_brushfire(ms, w, "first build")
+    half = cells * 0.1 / 2.0
+    extra = [(0.25 * half, 0.05 * half, [0.31 * half, -0.22 * half, 0.4]), (0.2 * half, 0.03 * half, [-0.4 * half, 0.35 * half, -1.1])]
+    ids, total = [], first
+    for k, (dx, dy, pose) in enumerate(extra):  # AddObstacle
+        ident = w.add_rectangle(dx, dy, pose)
+        ids.append(ident)
+        ms.add_polygon(rect_vertices(dx, dy), pose, ident)
+        w.update()
+        pops = ms.update_gvd(mode=ms.GVD_REFERENCE_ORDER)
+        assert_fields_equal_the_brushfire(ms, w, "after adding %d" % k)
+        assert pops - total < first // 2  # incremental: a fraction of the first sweep
+        total = pops
+    # RemoveObstacle of the first added one (its outline crosses nothing else here), then of an original rectangle
+    w.remove_rectangle(ids[0], extra[0][0], extra[0][1], extra[0][2])
+    ms.add_polygon(rect_vertices(extra[0][0], extra[0][1]), extra[0][2], -1)
+    w.update()
+    ms.update_gvd(mode=ms.GVD_REFERENCE_ORDER)
+    assert_fields_equal_the_brushfire(ms, w, "after removing the added rectangle")
+    k = next(i for i, sh in enumerate(shapes) if sh[0] == "rect")
+    w.remove_rectangle(k, shapes[k][1], shapes[k][2], shapes[k][3])
+    ms.add_polygon(rect_vertices(shapes[k][1], shapes[k][2]), shapes[k][3], -1)
+    w.update()
+    ms.update_gvd(mode=ms.GVD_REFERENCE_ORDER)
+    assert_fields_equal_the_brushfire(ms, w, "after removing an original rectangle")
+    assert np.array_equal(ms.download_occupancy(), w.occ())
+
+
 def test_gvd_update_against_the_brushfire():
     from scipy import ndimage
     report = {}
@@ -86,7 +154,7 @@ def test_gvd_update_against_the_brushfire():
         g = ms.download_gvd()
         d2, ref = g["d2"].astype(np.int64), w.d2().astype(np.int64)
         edt = ndimage.distance_transform_edt(w.occ() < 0)
-        assert np.array_equal(d2, np.rint(edt * edt).astype(np.int64))  # the fixed point is the exact transform here
+        assert np.array_equal(d2, np.rint(edt * edt).astype(np.int64))  # an exact transform
         assert (d2 <= ref).all()  # the brushfire's values are distances to real obstacle cells: never below the minimum
         diff = d2 != ref
         assert diff.mean() < 2e-3 and (np.sqrt(ref) - np.sqrt(d2)).max() < 0.05  # a twentieth of a cell at most, on < 0.2 % of the cells
@@ -110,7 +178,7 @@ def test_gvd_update_against_the_brushfire():
         # a Voronoi mark that differs moves the potential of the cells around it (voroDist / (obstDist + voroDist) jumps at an
         # edge cell): few cells, bounded on average
         assert np.abs(pc - ref_pc).mean() < 2e-3 and (np.abs(pc - ref_pc) > 0.02).mean() < 0.02
-        report[str(cells)] = dict(propagation_steps=steps, d2_cells_differing=int(diff.sum()), d2_max_diff=int((ref - d2).max()), cells=cells * cells,
+        report[str(cells)] = dict(device_passes=steps, d2_cells_differing=int(diff.sum()), d2_max_diff=int((ref - d2).max()), cells=cells * cells,
                                   voronoi_edges_device=int(edge.sum()), voronoi_edges_brushfire=int(ref_edge.sum()), voronoi_edges_common=int(both),
                                   voronoi_d2_equal_fraction=float((g["voronoi_d2"] == w.voro_d2()).mean()), path_cost_bits_equal_fraction=float((pc.view(np.uint32) == ref_pc.view(np.uint32)).mean()),
                                   path_cost_max_abs_diff=float(np.abs(pc - ref_pc).max()), path_cost_mean_abs_diff=float(np.abs(pc - ref_pc).mean()))

@@ -38,6 +38,54 @@ def test_names_match_reference_bindings(nav):
     assert p.wheelbase == 2.6 and p.num_generated_motion == 5 and p.angular_resolution == 0.0872
 
 
+def test_every_name_the_reference_module_binds_is_bound(nav):
+    """tests/golden/pyplanning_bound_names.json = the class, enum, method, property and value NAMES extracted from the reference's
+    interfaces/python/src/pyplanning.cpp by tests/golden/make_pyplanning_names.py (118 members of 42 classes): none may be missing
+    here -- including the typo'd "is_occupied)" (pyplanning.cpp:351), which a caller of the reference can only reach by getattr."""
+    import json
+    import os
+    names = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pyplanning_bound_names.json")))
+    assert len(names["classes"]) >= 42
+    missing = [n for n in names["module"] if not hasattr(nav, n)]
+    for cls, info in names["classes"].items():
+        if not hasattr(nav, cls):
+            missing.append(cls)
+            continue
+        missing += ["%s.%s" % (cls, m) for m in info["members"] if not hasattr(getattr(nav, cls), m)]
+    assert missing == []
+    m = nav.OccupancyMap(0.5)
+    m.initialize_size(8.0, 8.0)
+    assert getattr(m, "is_occupied)")(nav.GridCellPosition(1, 1)) == m.is_occupied(nav.GridCellPosition(1, 1))
+    with pytest.raises(TypeError):  # as in the reference: the return type is not a bound class
+        m.get_obstacle_map()
+
+
+def test_state_space_samplers_follow_the_reference_random(nav):
+    """StateSpaceSE2::SampleUniform / SampleGaussian (state_space_se2.cpp:27-52, pyplanning.cpp:325-326) on the global mt19937_64 of
+    utils/random.h: with the same seed, the stream of the reference's own random.h (compiled into oracle/_ref)."""
+    import ctypes as C
+    import os
+    import oracle_lib as O
+    ref_so = os.path.join(O.ORACLE_DIR, "_ref", "libppref.so")
+    if not os.path.exists(ref_so):
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    ref = C.CDLL(ref_so)
+    lb, ub = np.array([-51.2, -20.0, -np.pi]), np.array([51.2, 30.0, np.pi])
+    mean, std = np.array([1.0, -2.0, 0.3]), np.array([40.0, 0.5, 2.5])
+    n = 500
+    uni, gau = np.empty((n, 3)), np.empty((n, 3))
+    ref.ref_rng_se2.argtypes = [C.c_ulonglong, C.c_longlong] + [C.POINTER(C.c_double)] * 6
+    ref.ref_rng_se2(C.c_ulonglong(2024), C.c_longlong(n), O.dptr(lb), O.dptr(ub), O.dptr(mean), O.dptr(std), O.dptr(uni), O.dptr(gau))
+    ss = nav.StateSpaceSE2(nav.Pose2d(*lb), nav.Pose2d(*ub))
+    nav.seed_random(2024)
+    got_u = np.array([[p.x(), p.y(), p.theta] for p in (ss.sample_uniform() for _ in range(n))])
+    got_g = np.array([[p.x(), p.y(), p.theta] for p in (ss.sample_gaussian(nav.Pose2d(*mean), nav.Pose2d(*std)) for _ in range(n))])
+    assert np.array_equal(got_u, uni)
+    assert np.array_equal(got_g, np.clip(gau, lb, ub))  # EnforceBounds (std::clamp per component)
+    assert (np.clip(gau, lb, ub) != gau).any()  # the clamp is exercised
+    assert all(ss.validate_bounds(nav.Pose2d(*r)) for r in got_u[:20])
+
+
 def test_host_side_value_types(nav):
     a = nav.Pose2d(1.0, 2.0, 7.0)  # constructor wraps theta (geometry/2dplane.h:19-22)
     assert abs(a.theta - (7.0 - 2 * np.pi)) < 1e-15
