@@ -257,6 +257,11 @@ int pp_planner_destroy(pp_planner* planner);
 int pp_planner_set_nonholo_table(pp_planner* planner, const double* table_host);
 int pp_planner_get_nonholo_table(pp_planner* planner, double* table_host);
 int pp_planner_num_primitives(pp_planner* planner);
+/* Replaces StatePropagator::m_deltas (algo/hybrid_a_star.cpp:21-28 generates {0, +-0.5 dMax, +-1.0 dMax, ...} from num_generated_motion,
+ * which can only give 2 * odd primitives): any list of steering angles [rad]; every angle gives a forward and a backward primitive,
+ * children in list order, forward first (hybrid_a_star.cpp:65-77).  36 angles = the "72 motion primitives" of BASELINE config 2.
+ * Waits for the planner's stream; applies from the next batch on. */
+int pp_planner_set_primitives(pp_planner* planner, int32_t n_steering_angles, const double* steering_angles);
 
 typedef struct pp_query_result {
 	int32_t status;        /* 0 = Success, -1 = Failure (algo/path_planner.h:9-12), -4 = node capacity exceeded */

@@ -387,7 +387,11 @@ void ppo_se2_paths_valid(void* wv, int64_t n, const double* from, const double* 
 }
 
 /// sensitivity probe of the smoother's curvature term (ppo_post.hpp: Smoother::LibmLastBit)
-void ppo_smoother_libm_last_bit(int shift) { Smoother::LibmLastBit() = shift; }
+void ppo_smoother_libm_last_bit(int shift)
+{
+	Smoother::LibmLastBit() = shift;
+	Smoother::ProbeCounter() = 0;
+}
 
 // --------------------------------------------- post-processing + smoother ----
 struct PostHandle {
@@ -612,6 +616,9 @@ void ppo_hybrid_deltas(void* hv, double* out)
 	for (size_t i = 0; i < d.size(); i++)
 		out[i] = d[i];
 }
+/// Replaces m_deltas (hybrid_a_star.cpp:21-28 can only generate {0, +-0.5 dMax, +-1.0 dMax, ...}, i.e. 2 * odd primitives): any list of
+/// steering angles, children in list order, forward then backward each (hybrid_a_star.cpp:65-77) -- SURVEY 8d config 2's "P = 72"
+void ppo_hybrid_set_deltas(void* hv, int n, const double* deltas) { ((HybridHandle*)hv)->algo->deltas.assign(deltas, deltas + n); }
 void ppo_hybrid_set_max_expansions(void* hv, int64_t n) { ((HybridHandle*)hv)->algo->maxExpansions = n < 0 ? (size_t)-1 : (size_t)n; }
 /// Runs ObstaclesHeuristic::Update for `goal` and sets both heuristics' goal.
 void ppo_hybrid_set_goal(void* hv, const double* goal)

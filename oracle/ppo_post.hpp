@@ -156,13 +156,19 @@ struct Smoother {
 				return false;
 		return true;
 	}
-	/// 0: the restatement as it is.  +1 / -1: every cosine of the curvature term is moved one ulp up / down -- what another libm
+	/// 0: the restatement as it is.  +1 / -1: every cosine of the curvature term is moved one ulp up / down (|k| >= 2: up or down per
+	/// call, pseudo-randomly, a different sequence per k) -- what another libm
 	/// build (glibc selects FMA or SSE2 variants of cos per CPU) may legitimately return.  A query whose smoothed path moves by
 	/// more than the parity tolerance under this probe has no machine-independent reference result.
 	static int& LibmLastBit()
 	{
 		static int v = 0;
 		return v;
+	}
+	static uint64_t& ProbeCounter()
+	{
+		static uint64_t c = 0;
+		return c;
 	}
 	void CurvatureTerm(const V2& xim1, const V2& xi, const V2& xip1, V2& gim1, V2& gi, V2& gip1) const
 	{
@@ -184,8 +190,16 @@ struct Smoother {
 		V2 DcosDeltaPhi_DdeltaXi { oc1.x / denominator, oc1.y / denominator };
 		V2 DcosDeltaPhi_DdeltaXip1 { oc2.x / denominator, oc2.y / denominator };
 		double cosDeltaPhi = ::cos((double)deltaPhi);
-		if (LibmLastBit() != 0) // sensitivity probe (tests only): the cosine moved by one unit in the last place
-			cosDeltaPhi = std::nextafter(cosDeltaPhi, LibmLastBit() > 0 ? 2.0 : -2.0);
+		if (LibmLastBit() != 0) { // sensitivity probe (tests only): the cosine moved by one unit in the last place
+			bool up = LibmLastBit() > 0;
+			if (LibmLastBit() > 1 || LibmLastBit() < -1) { // |k| >= 2: up or down per call, a fixed pseudo-random sequence per k
+				uint64_t z = (ProbeCounter()++ + (uint64_t)(int64_t)LibmLastBit()) * 0x9E3779B97F4A7C15ull;
+				z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+				z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+				up = ((z ^ (z >> 31)) & 1ull) != 0;
+			}
+			cosDeltaPhi = std::nextafter(cosDeltaPhi, up ? 2.0 : -2.0);
+		}
 		float DdeltaPhi_DcosDeltaPhi = -1.0f / ::sqrt(1.0f - std::pow(cosDeltaPhi, 2));
 		float coef1 = 1 / deltaXi.norm() * DdeltaPhi_DcosDeltaPhi;
 		V2 nrm = deltaXi.normalized();
@@ -235,6 +249,16 @@ struct Smoother {
 			indices.push_back(i + 2);
 		}
 		current = path;
+		if (LibmLastBit() > 1 || LibmLastBit() < -1) { // sensitivity probe: the sampled points come out of sin / cos (arc and Reeds-Shepp
+			// interpolation), whose last bit is libm's: every coordinate one ulp up or down, pseudo-randomly
+			for (auto& pose : current) {
+				uint64_t z = (ProbeCounter()++ + 77u * (uint64_t)(int64_t)LibmLastBit()) * 0x9E3779B97F4A7C15ull;
+				z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+				z ^= z >> 27;
+				pose.x = std::nextafter(pose.x, (z & 1ull) ? 1e300 : -1e300);
+				pose.y = std::nextafter(pose.y, (z & 2ull) ? 1e300 : -1e300);
+			}
+		}
 		std::vector<V2> gradients((size_t)num);
 		const float unsafeRadius = world->minSafeRadius * (1 + p.collisionRatio);
 		int count = -1;

@@ -149,6 +149,7 @@ def load():
     L.pp_planner_set_nonholo_table.argtypes = [vp, vp]
     L.pp_planner_get_nonholo_table.argtypes = [vp, vp]
     L.pp_planner_num_primitives.argtypes = [vp]
+    L.pp_planner_set_primitives.argtypes = [vp, C.c_int32, vp]
     L.pp_planner_search_batch.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     L.pp_planner_search_batch_dev.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.pp_planner_fetch_results.argtypes = [vp, C.c_int32, vp]

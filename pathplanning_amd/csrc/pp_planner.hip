@@ -1197,6 +1197,33 @@ int warm_up_kernels(pp_planner* p, pp_map* map)
 	return PP_OK;
 }
 
+/// The primitive table of the search kernels from the steering-angle list (StatePropagator::m_deltas): children in list order,
+/// forward then backward each (hybrid_a_star.cpp:65-77); curvature per primitive with the host's libm
+int primitives_from_deltas(pp_planner* p)
+{
+	const int P = 2 * (int)p->deltas.size();
+	if (P < 2 || P > pph::kMaxPrimitives) {
+		set_error("between 1 and " + std::to_string(pph::kMaxPrimitives / 2) + " steering angles (two motion primitives each)");
+		return PP_ERR_INVALID;
+	}
+	const double wheelbase = p->params.wheelbase, rearToCenter = 0.0;
+	pph::PrimTable& T = p->args.prims;
+	T.n = P;
+	for (size_t d = 0; d < p->deltas.size(); d++) {
+		// ConstantSteer, kinematic_bicycle_model.cpp:13-17 with rearToCenter = 0
+		const double tanSteering = std::tan(p->deltas[d]);
+		const double beta = std::atan(rearToCenter * tanSteering / wheelbase);
+		const double cosBeta = std::cos(beta);
+		const double DthetaDdist = cosBeta * tanSteering / wheelbase;
+		T.kappa[2 * d] = DthetaDdist;
+		T.invKappa[2 * d] = T.invKappa[2 * d + 1] = DthetaDdist != 0.0 ? 1 / DthetaDdist : 0.0;
+		T.backward[2 * d] = 0;
+		T.kappa[2 * d + 1] = DthetaDdist;
+		T.backward[2 * d + 1] = 1;
+	}
+	return PP_OK;
+}
+
 void free_planner(pp_planner* p)
 {
 	if (!p)
@@ -1276,26 +1303,11 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		p->deltas.push_back(delta);
 		p->deltas.push_back(-delta);
 	}
-	const int P = 2 * (int)p->deltas.size();
-	if (P > pph::kMaxPrimitives) {
-		set_error("too many motion primitives");
-		free_planner(p);
-		return PP_ERR_INVALID;
-	}
 	SearchArgs& A = p->args;
 	A.m = map->view();
-	A.prims.n = P;
-	for (size_t d = 0; d < p->deltas.size(); d++) {
-		// ConstantSteer, kinematic_bicycle_model.cpp:13-17 with rearToCenter = 0
-		const double tanSteering = std::tan(p->deltas[d]);
-		const double beta = std::atan(rearToCenter * tanSteering / wheelbase);
-		const double cosBeta = std::cos(beta);
-		const double DthetaDdist = cosBeta * tanSteering / wheelbase;
-		A.prims.kappa[2 * d] = DthetaDdist;
-		A.prims.invKappa[2 * d] = A.prims.invKappa[2 * d + 1] = DthetaDdist != 0.0 ? 1 / DthetaDdist : 0.0;
-		A.prims.backward[2 * d] = 0;
-		A.prims.kappa[2 * d + 1] = DthetaDdist;
-		A.prims.backward[2 * d + 1] = 1;
+	if (int rc = primitives_from_deltas(p)) {
+		free_planner(p);
+		return rc;
 	}
 	A.rp.arcLength = params->spatial_resolution * 1.5;
 	A.rp.spatialRes = params->spatial_resolution;
@@ -1511,6 +1523,24 @@ int pp_planner_destroy(pp_planner* planner)
 }
 
 int pp_planner_num_primitives(pp_planner* planner) { return planner ? planner->args.prims.n : 0; }
+
+int pp_planner_set_primitives(pp_planner* planner, int32_t n_steering_angles, const double* steering_angles)
+{
+	if (!planner || !steering_angles || n_steering_angles < 1) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	PP_HIP_TRY(hipStreamSynchronize(planner->map->ctx->stream)); // a batch in flight keeps the table it was launched with
+	const std::vector<double> before = planner->deltas;
+	planner->deltas.assign(steering_angles, steering_angles + n_steering_angles);
+	if (int rc = primitives_from_deltas(planner)) {
+		planner->deltas = before;
+		(void)primitives_from_deltas(planner);
+		return rc;
+	}
+	return PP_OK;
+}
 
 int pp_planner_set_nonholo_table(pp_planner* planner, const double* table_host)
 {

@@ -466,6 +466,12 @@ class HybridAStarBatch:
         self._results = None
         self.is_initialized = False
 
+    def set_primitives(self, steering_angles):
+        """Explicit steering-angle list instead of the one hybrid_a_star.cpp:21-28 generates (P = 2 * len: forward + backward each)."""
+        d = np.ascontiguousarray(steering_angles, dtype=np.float64)
+        check(self.lib.pp_planner_set_primitives(self.h, len(d), ptr(d)))
+        self.num_primitives = self.lib.pp_planner_num_primitives(self.h)
+
     def initialize(self, nonholo_table=None):
         """HybridAStar::Initialize (hybrid_a_star.cpp:206-235): builds the non-holonomic table on the
         device unless one is supplied."""

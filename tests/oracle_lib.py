@@ -367,6 +367,12 @@ class Hybrid:
         lib().ppo_hybrid_children(self.h, C.c_int64(n), dptr(parents), u8ptr(valid), dptr(poses), iptr(keys), dptr(cost), dptr(length))
         return dict(valid=valid, poses=poses, keys=keys, cost=cost, length=length)
 
+    def set_deltas(self, deltas):
+        """explicit steering-angle list instead of the generated one (P = 2 * len(deltas))"""
+        d = np.ascontiguousarray(deltas, dtype=np.float64)
+        lib().ppo_hybrid_set_deltas(self.h, C.c_int(len(d)), dptr(d))
+        self.P = 2 * len(d)
+
     def set_max_expansions(self, n):
         lib().ppo_hybrid_set_max_expansions(self.h, C.c_int64(n))
 

@@ -319,6 +319,34 @@ def test_config2_query_at_74_primitives_both_kernels(monkeypatch, rows_kernel):
     assert res[0].status == 0 and res[0].n_expanded > 200
 
 
+@pytest.mark.parametrize("rows_kernel", ["0", "1"])
+def test_config2_query_with_an_explicit_table_of_72_primitives(monkeypatch, rows_kernel):
+    """BASELINE config 2 names 72 motion primitives; hybrid_a_star.cpp:21-28 can only generate 2 * odd.  pp_planner_set_primitives
+    takes the steering-angle list itself (36 angles, forward + backward each); the oracle gets the same list in place of m_deltas.
+    Expansion sequence, counters, cost and path as for every other primitive count, through both search kernels."""
+    monkeypatch.setenv("PP_SEARCH_ROWS", rows_kernel)
+    import pathplanning_amd as pa
+    w, ms, val, ctx = make_pair(512, 12, 1)
+    starts = np.array([[-23.04, -23.04, 0.0], [20.3, -21.7, 2.0]])
+    goals = np.array([[23.04, 23.04, 0.0], [-20.1, 19.4, -1.0]])
+    seeds = np.array([12345, 12346], dtype=np.uint64)
+    P = pa.HybridAStarSearchParameters()
+    delta_max = math.atan(P.wheelbase / P.min_turning_radius)
+    deltas = np.linspace(-delta_max, delta_max, 36)
+    planner = pa.HybridAStarBatch(val, P, max_batch=2, max_nodes=131072)
+    planner.set_primitives(deltas)
+    assert planner.num_primitives == 72
+    planner.initialize()
+    res = planner.search_batch(starts, goals, seeds)
+    h = O.Hybrid(w, O.params_array(), table=planner.nonholo_table())
+    h.set_deltas(deltas)
+    assert h.P == 72
+    assert compare(planner, res, h, starts, goals, seeds) >= 1
+    assert res[0].status == 0 and res[0].n_expanded > 200
+    with pytest.raises(Exception):
+        planner.set_primitives(np.zeros(65))  # 130 primitives: beyond the table
+
+
 def test_planners_until_capacity_error_not_an_abort():
     """Round 1's abort (gpurun_out/b_b2048.log): a planner took the last byte of HBM and the runtime could not allocate the
     scratch k_wavefront needs at its first dispatch -> HSA_STATUS_ERROR_OUT_OF_RESOURCES, core dump.  Now the kernels are
