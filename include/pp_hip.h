@@ -324,6 +324,37 @@ int pp_planner_get_processed_path(pp_planner* planner, int32_t q, double* sample
 /* (row, col) per cell, row-major, (-1, -1) = none: the two label grids of the reference's GVD for maps whose fields were built elsewhere */
 int pp_map_upload_nearest_cells(pp_map* map, const int32_t* nearest_obstacle_host, const int32_t* nearest_edge_host);
 
+/* ---- streaming form of HybridAStar::SearchPath's search stage (algo/hybrid_a_star.cpp:237-257) ------------------------------
+ * One pipeline per GPU: `capacity` queries in flight (a field slot each: the obstacle-heuristic field of its goal, start / goal /
+ * seed, path and Reeds-Shepp log), ObstaclesHeuristic::Update by the wavefront kernel, which hands every finished field to ONE
+ * persistent search grid of `search_rows` rows (0 = 2048) through a device-side queue; a row takes the next ready query as soon as
+ * its own ends, slots are recycled as results are polled.  No batch boundary: a query that exhausts the lattice (~1 s) holds one
+ * row, not a batch's 17 GB of fields.  Results per query are exactly those of pp_planner_search_batch (same kernels' device code).
+ * log_expansions != 0 keeps the expansion log per slot (parity tests; 4 B x max_nodes_per_query per slot).
+ * Not thread-safe per pipeline.  Set GPU_MAX_HW_QUEUES >= 8 before the HIP runtime starts: the pipeline's kernels run on seven
+ * streams, and two streams that share a hardware queue serialise (the grid then falls back on its idle time-out, PP_PIPE_IDLE_MS). */
+typedef struct pp_pipeline pp_pipeline;
+int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capacity, int32_t max_nodes_per_query, int32_t search_rows, int32_t log_expansions,
+	pp_pipeline** out);
+int pp_pipeline_destroy(pp_pipeline* pipeline);
+/* Takes up to n_queries queries (as many as there are free slots: *n_accepted; submit the rest after a poll has released slots).
+ * tickets_out (may be NULL): one id per accepted query, in input order.  The input arrays are free when the call returns. */
+int pp_pipeline_submit_dev(pp_pipeline* pipeline, int32_t n_queries, const double* starts_dev, const double* goals_dev, const uint64_t* seeds_dev, uint64_t* tickets_out,
+	int32_t* n_accepted);
+int pp_pipeline_submit(pp_pipeline* pipeline, int32_t n_queries, const double* starts_host, const double* goals_host, const uint64_t* seeds_host, uint64_t* tickets_out,
+	int32_t* n_accepted);
+/* Completed queries, at most max_results, in completion order; never blocks.  release != 0: their slots are free again at once;
+ * release == 0: a slot stays held (pp_pipeline_slot_of + the pp_planner_get_path / get_expanded accessors of pp_pipeline_planner
+ * read its path) until pp_pipeline_release. */
+int pp_pipeline_poll(pp_pipeline* pipeline, int32_t max_results, uint64_t* tickets_out, pp_query_result* results_out, int32_t release, int32_t* n_out);
+int pp_pipeline_release(pp_pipeline* pipeline, int32_t n, const uint64_t* tickets);
+int pp_pipeline_slot_of(pp_pipeline* pipeline, uint64_t ticket); /* -1 unless completed and held */
+pp_planner* pp_pipeline_planner(pp_pipeline* pipeline);           /* the buffer set: set_nonholo_table, set_primitives, get_path(slot), ... */
+int pp_pipeline_capacity(pp_pipeline* pipeline);
+int pp_pipeline_search_rows(pp_pipeline* pipeline);
+int pp_pipeline_in_flight(pp_pipeline* pipeline);  /* submitted and not yet polled */
+int pp_pipeline_free_slots(pp_pipeline* pipeline);
+
 /* last batch: milliseconds spent in the wavefront kernel and in the search kernel (HIP events) */
 int pp_planner_last_timings(pp_planner* planner, float* wavefront_ms, float* search_ms);
 /* Diagnostics (never on by default): launch the stamped build of the search kernel and read, per query,

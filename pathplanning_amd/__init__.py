@@ -5,4 +5,4 @@ C ABI (include/pp_hip.h); planner.py mirrors the reference's operator interface 
 """
 from . import _lib  # noqa: F401
 from .planner import (Context, OccupancyMapSet, StateValidatorOccupancyMap, HybridAStarBatch, ReedsSheppSolver,  # noqa: F401
-                      ObstaclesHeuristic, NonHolonomicHeuristic, ReedsSheppPaths, Tree, Status, HybridAStarSearchParameters, RRT, RRTStar, GridAStarBatch)
+                      ObstaclesHeuristic, NonHolonomicHeuristic, ReedsSheppPaths, Tree, Status, HybridAStarSearchParameters, HybridAStarPipeline, RRT, RRTStar, GridAStarBatch)

@@ -6,6 +6,10 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# The streaming pipeline (pp_pipeline_*) and bench.py keep several kernels running side by side on their own streams; the runtime maps
+# streams onto 4 hardware queues by default, and two streams that share a queue serialise.  Read when the HIP runtime starts, so
+# it only takes effect if nothing has touched the GPU yet (set it in the environment otherwise).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 # PP_HIP_LIB: another build of the same library (tuning experiments: tools/build_variant.py)
 LIB_PATH = os.environ.get("PP_HIP_LIB") or os.path.join(HERE, "lib", "libpphip.so")
 
@@ -155,6 +159,17 @@ def load():
     L.pp_planner_fetch_results.argtypes = [vp, C.c_int32, vp]
     L.pp_planner_get_path.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
     L.pp_planner_get_expanded.argtypes = [vp, C.c_int32, vp]
+    L.pp_pipeline_create.argtypes = [vp, C.POINTER(HybridParams), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
+    L.pp_pipeline_destroy.argtypes = [vp]
+    L.pp_pipeline_submit_dev.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
+    L.pp_pipeline_submit.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
+    L.pp_pipeline_poll.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
+    L.pp_pipeline_release.argtypes = [vp, C.c_int32, vp]
+    L.pp_pipeline_slot_of.argtypes = [vp, C.c_uint64]
+    L.pp_pipeline_planner.argtypes = [vp]
+    L.pp_pipeline_planner.restype = vp
+    for f in ("pp_pipeline_capacity", "pp_pipeline_search_rows", "pp_pipeline_in_flight", "pp_pipeline_free_slots"):
+        getattr(L, f).argtypes = [vp]
     L.pp_planner_postprocess.argtypes = [vp, C.c_int32, C.c_float, vp, C.c_int32, vp]
     L.pp_planner_get_processed_path.argtypes = [vp, C.c_int32, vp, vp, vp]
     L.pp_map_upload_nearest_cells.argtypes = [vp, vp, vp]

@@ -79,10 +79,18 @@ hipError_t warm_up_wavefront(hipStream_t s, const ppd::MapView& m, int32_t* ctlD
 /// countersZeroed: the caller has already cleared errorFlagDev[0..1] on the stream.
 /// tiledOut: costDev is [nGoals][field_tiled_elems] in the 8 x 8-tiled layout of pp_device.hpp (what the search kernel
 /// reads); otherwise [nGoals][rows*cols] row-major (the public a8 entry points).
+/// Pipeline use of the wavefront kernel (pp_pipeline.hpp): entry i of a launch works on field slot slotList[i] (goal pose and output
+/// field are indexed by the slot), and every finished slot is appended to the ready ring the search grid consumes.
+struct WavefrontPublish {
+	const int32_t* slotList = nullptr;
+	unsigned long long* readyTail = nullptr; // entries appended so far (absolute)
+	unsigned long long* ready = nullptr;     // ring of (position + 1) << 32 | slot
+	unsigned long long readyMask = 0;        // ring size - 1 (a power of two)
+};
 hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
 	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev = nullptr, bool tiledOut = false,
 	const double* goalPosesDev = nullptr, bool countersZeroed = false, const double* orderStartsDev = nullptr, int32_t* orderOutDev = nullptr,
-	int* doneCounterDev = nullptr, float* orderKeysDev = nullptr);
+	int* doneCounterDev = nullptr, float* orderKeysDev = nullptr, const WavefrontPublish& pub = WavefrontPublish());
 
 } // namespace pph
 

@@ -1,0 +1,434 @@
+// pp_pipeline -- HybridAStar::SearchPath (algo/hybrid_a_star.cpp:237-257: ObstaclesHeuristic::Update for the goal, then the graph
+// search) for a STREAM of independent queries: one persistent search grid per GPU fed by the wavefront kernel through a device-side
+// queue, field slots recycled as queries end.
+//
+// Included by pp_planner.hip (it shares that file's kernels and buffer set).
+//
+// Why: the batch planner (pp_planner_search_batch_dev) runs "all wavefronts of a batch, then all searches of that batch"; a batch lasts as
+// long as its longest query (a query that exhausts the lattice takes ~1 s while the mean takes a few ms), so most of a planner's rows
+// idle while its 17 GB of fields wait, and hiding that took eight planners, a refill loop and a measured start stagger in bench.py
+// (round 2).  Here there is no batch boundary:
+//   * `capacity` field slots (one obstacle-heuristic field, start / goal / seed, path and Reeds-Shepp log each); a submitted query takes
+//     a free slot;
+//   * the wavefront kernel builds the slots' fields (one launch per submission, two streams so that consecutive launches overlap) and
+//     appends every finished slot to the READY RING (agent-scope release, stamped entries);
+//   * the rows of the search grid (k_hybrid_search_rows, pp_planner_rows.hpp use (c)) claim slots from the ring as they become free -- a
+//     row is busy as long as anything is ready, whatever its neighbours in the wave are doing, and a long query holds one row, not a batch;
+//   * a finished query's record goes to a ring in pinned host memory; pp_pipeline_poll hands records out and returns their slots to the
+//     free list.
+// The search grid is "persistent" only while there is work: a wave leaves when every submitted query has been claimed and its rows are
+// idle (or after `idleTicks` without work -- no wave waits for ever on a producer that cannot run), and every submission launches the
+// grid again; a wave of the new launch whose index is still owned by an older wave leaves at once (PipeView::waveAlive).  So no host
+// thread, no spin on host memory, and a device synchronisation returns as soon as the submitted work is done.
+#pragma once
+
+#include <chrono>
+#include <unordered_map>
+
+namespace {
+
+/// start / goal / seed of a submission into their field slots
+__global__ void __launch_bounds__(256) k_pipe_scatter(int n, const int32_t* __restrict__ slotList, const double* __restrict__ startsIn, const double* __restrict__ goalsIn,
+	const uint64_t* __restrict__ seedsIn, double* __restrict__ starts, double* __restrict__ goals, uint64_t* __restrict__ seeds)
+{
+	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (i >= n)
+		return;
+	const size_t s = (size_t)slotList[i];
+	for (int k = 0; k < 3; k++) {
+		starts[3 * s + k] = startsIn[3 * (size_t)i + k];
+		goals[3 * s + k] = goalsIn[3 * (size_t)i + k];
+	}
+	seeds[s] = seedsIn[i];
+}
+
+constexpr int kPipeSearchStreams = 4;
+constexpr int kPipeWavefrontStreams = 2;
+
+} // namespace
+
+struct pp_pipeline {
+	pp_planner* pl = nullptr; // the buffer set: fields, per-slot inputs / paths / logs, the rows' node / heap / key-map buffers
+	int capacity = 0;
+	int waves = 0; // waves of the search grid (= rows / 4)
+	// device
+	PipeCtl* ctl = nullptr;
+	unsigned long long* ready = nullptr;
+	unsigned long long readyMask = 0;
+	int* waveAlive = nullptr;
+	int32_t* slotLists = nullptr; // ring of slot lists, one segment per wavefront launch in flight
+	size_t slotListCap = 0, slotListPos = 0;
+	void* wfWorkspace[kPipeWavefrontStreams] = {};
+	int32_t* wfCtl[kPipeWavefrontStreams] = {}; // {error flag, goal counter} per wavefront stream
+	// pinned host
+	PipeDone* done = nullptr;
+	unsigned long long doneMask = 0;
+	int32_t* slotStage = nullptr;             // staging of the slot lists (same ring positions as slotLists)
+	unsigned long long* submittedStage = nullptr; // ring of submission counts on their way to ctl->nSubmitted
+	int submittedStagePos = 0;
+	int32_t* errStage = nullptr; // copies of the wavefront error flags, refreshed by every poll
+	// streams
+	hipStream_t wfStream[kPipeWavefrontStreams] = {}, searchStream[kPipeSearchStreams] = {}, ctlStream = nullptr;
+	hipEvent_t evIngest = nullptr, evCtl = nullptr;
+	int nextWf = 0, nextSearch = 0;
+	// host bookkeeping
+	std::vector<int32_t> freeSlots;
+	std::vector<uint64_t> ticketOfSlot;
+	std::vector<uint8_t> slotState; // 0 free, 1 in flight, 2 completed and held for the caller
+	std::unordered_map<uint64_t, int32_t> slotOfTicket;
+	unsigned long long nSubmitted = 0, doneHead = 0, nTickets = 0;
+	std::chrono::steady_clock::time_point lastLaunch {};
+	unsigned long long idleTicks = 12500ull; // idle loop passes of ~4 us: about 50 ms
+};
+
+namespace {
+
+void free_pipeline(pp_pipeline* P)
+{
+	if (!P)
+		return;
+	for (hipStream_t s : P->wfStream)
+		if (s)
+			(void)hipStreamDestroy(s);
+	for (hipStream_t s : P->searchStream)
+		if (s)
+			(void)hipStreamDestroy(s);
+	if (P->ctlStream)
+		(void)hipStreamDestroy(P->ctlStream);
+	if (P->evIngest)
+		(void)hipEventDestroy(P->evIngest);
+	if (P->evCtl)
+		(void)hipEventDestroy(P->evCtl);
+	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfCtl[0], P->wfCtl[1] };
+	for (void* q : dev)
+		if (q)
+			(void)hipFree(q);
+	void* host[] = { P->done, P->slotStage, P->submittedStage, P->errStage };
+	for (void* q : host)
+		if (q)
+			(void)hipHostFree(q);
+	if (P->pl)
+		free_planner(P->pl);
+	delete P;
+}
+
+PipeView pipe_view(const pp_pipeline* P)
+{
+	PipeView v;
+	v.ctl = P->ctl;
+	v.ready = P->ready;
+	v.readyMask = P->readyMask;
+	v.done = P->done;
+	v.doneMask = P->doneMask;
+	v.waveAlive = P->waveAlive;
+	v.idleTicks = P->idleTicks;
+	return v;
+}
+
+/// the submission count goes to the device on the control stream, then a launch of the whole grid behind it: waves whose index is
+/// free start working, the others leave at once
+int pipe_launch_search(pp_pipeline* P)
+{
+	pp_planner* pl = P->pl;
+	unsigned long long* const src = P->submittedStage + (P->submittedStagePos++ & 63);
+	*src = P->nSubmitted;
+	PP_HIP_TRY(hipMemcpyAsync(&P->ctl->nSubmitted, src, 8, hipMemcpyHostToDevice, P->ctlStream));
+	PP_HIP_TRY(hipEventRecord(P->evCtl, P->ctlStream));
+	hipStream_t s = P->searchStream[P->nextSearch];
+	P->nextSearch = (P->nextSearch + 1) % kPipeSearchStreams;
+	PP_HIP_TRY(hipStreamWaitEvent(s, P->evCtl, 0));
+	constexpr int kWg = PP_ROWS_WAVES_PER_WG;
+	pl->args.rowsWaves = P->waves;
+	pl->args.m = pl->map->view(); // validator tunables may have changed
+	hipLaunchKernelGGL(k_hybrid_search_rows<true>, dim3((P->waves + kWg - 1) / kWg), dim3(64 * kWg), 0, s, pl->args, 0, pl->dStarts, pl->dGoals, pl->dSeeds, pl->costFields, pl->nodes, pl->heaps,
+		pl->keymaps, pl->expanded, pl->rsLogs, pl->paths, pl->mtStates, pl->results, (int*)nullptr, (SuspendRec*)nullptr, (const int32_t*)nullptr, 0, (const SuspendRec*)nullptr,
+		(const int*)nullptr, (int*)nullptr, (int*)nullptr, 0, pl->bands, pl->bandInvW, pl->bandMeta, pipe_view(P));
+	PP_HIP_TRY(hipGetLastError());
+	P->lastLaunch = std::chrono::steady_clock::now();
+	return PP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capacity, int32_t max_nodes_per_query, int32_t search_rows, int32_t log_expansions, pp_pipeline** out)
+{
+	if (!map || !params || !out || capacity < 4 || max_nodes_per_query < 16 || search_rows < 0) {
+		set_error("invalid arguments (capacity >= 4)");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(map->ctx->device));
+	auto* P = new pp_pipeline();
+	P->capacity = capacity;
+	if (search_rows == 0)
+		search_rows = 2048; // a quarter of the chip's resident rows: the wavefront kernel needs the other CUs
+	if (int rc = create_planner(map, params, capacity, max_nodes_per_query, search_rows, log_expansions ? PlannerUse::PipelineLogged : PlannerUse::Pipeline, &P->pl)) {
+		delete P;
+		return rc;
+	}
+	pp_planner* pl = P->pl;
+	P->waves = pl->searchRows / kRowsPerWave;
+	size_t ring = 4;
+	while (ring < (size_t)capacity * 2)
+		ring <<= 1;
+	P->readyMask = P->doneMask = ring - 1;
+	P->slotListCap = (size_t)capacity * 4;
+	hipError_t e = hipMalloc((void**)&P->ctl, sizeof(PipeCtl));
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&P->ready, ring * 8);
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&P->waveAlive, (size_t)P->waves * 4);
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&P->slotLists, P->slotListCap * 4);
+	for (int i = 0; i < kPipeWavefrontStreams && e == hipSuccess; i++) {
+		e = hipMalloc(&P->wfWorkspace[i], (size_t)pl->wfBytesPerSlot * pl->wfSlots);
+		if (e == hipSuccess)
+			e = hipMalloc((void**)&P->wfCtl[i], 32);
+		if (e == hipSuccess)
+			e = hipMemset(P->wfCtl[i], 0, 32);
+		if (e == hipSuccess)
+			e = hipStreamCreateWithFlags(&P->wfStream[i], hipStreamNonBlocking);
+	}
+	for (int i = 0; i < kPipeSearchStreams && e == hipSuccess; i++)
+		e = hipStreamCreateWithFlags(&P->searchStream[i], hipStreamNonBlocking);
+	if (e == hipSuccess)
+		e = hipStreamCreateWithFlags(&P->ctlStream, hipStreamNonBlocking);
+	if (e == hipSuccess)
+		e = hipEventCreateWithFlags(&P->evIngest, hipEventDisableTiming);
+	if (e == hipSuccess)
+		e = hipEventCreateWithFlags(&P->evCtl, hipEventDisableTiming);
+	if (e == hipSuccess)
+		e = hipHostMalloc((void**)&P->done, ring * sizeof(PipeDone), hipHostMallocDefault);
+	if (e == hipSuccess)
+		e = hipHostMalloc((void**)&P->slotStage, P->slotListCap * 4, hipHostMallocDefault);
+	if (e == hipSuccess)
+		e = hipHostMalloc((void**)&P->submittedStage, 64 * 8, hipHostMallocDefault);
+	if (e == hipSuccess)
+		e = hipHostMalloc((void**)&P->errStage, 64, hipHostMallocDefault);
+	if (e == hipSuccess)
+		e = hipMemset(P->ctl, 0, sizeof(PipeCtl));
+	if (e == hipSuccess)
+		e = hipMemset(P->ready, 0, ring * 8);
+	if (e == hipSuccess)
+		e = hipMemset(P->waveAlive, 0, (size_t)P->waves * 4);
+	if (e == hipSuccess)
+		e = hipDeviceSynchronize();
+	if (e != hipSuccess) {
+		free_pipeline(P);
+		return pph::hip_fail(e, "pipeline allocation");
+	}
+	std::memset(P->done, 0, ring * sizeof(PipeDone));
+	std::memset(P->errStage, 0, 64);
+	P->freeSlots.resize((size_t)capacity);
+	for (int i = 0; i < capacity; i++)
+		P->freeSlots[(size_t)i] = capacity - 1 - i; // slot 0 is handed out first
+	P->ticketOfSlot.assign((size_t)capacity, 0);
+	P->slotState.assign((size_t)capacity, 0);
+	pl->hostResults.resize((size_t)capacity);
+	pl->lastBatch = capacity;
+	{
+		const char* v = getenv("PP_PIPE_IDLE_MS"); // how long a wave waits for work that does not come before it leaves on its own
+		if (v && *v) {
+			const long ms = strtol(v, nullptr, 10);
+			P->idleTicks = (unsigned long long)(ms < 1 ? 1 : (ms > 10000 ? 10000 : ms)) * 250ull;
+		}
+	}
+	*out = P;
+	return PP_OK;
+}
+
+int pp_pipeline_destroy(pp_pipeline* P)
+{
+	if (!P)
+		return PP_OK;
+	(void)hipSetDevice(P->pl->map->ctx->device);
+	// waves that still wait for work leave at once; queries in flight are finished first
+	const int one = 1;
+	(void)hipMemcpyAsync(&P->ctl->stop, &one, 4, hipMemcpyHostToDevice, P->ctlStream);
+	(void)hipStreamSynchronize(P->ctlStream);
+	for (hipStream_t s : P->wfStream)
+		(void)hipStreamSynchronize(s);
+	for (hipStream_t s : P->searchStream)
+		(void)hipStreamSynchronize(s);
+	free_pipeline(P);
+	return PP_OK;
+}
+
+int pp_pipeline_capacity(pp_pipeline* P) { return P ? P->capacity : 0; }
+int pp_pipeline_search_rows(pp_pipeline* P) { return P ? P->pl->searchRows : 0; }
+int pp_pipeline_in_flight(pp_pipeline* P) { return P ? (int)(P->nSubmitted - P->doneHead) : 0; }
+int pp_pipeline_free_slots(pp_pipeline* P) { return P ? (int)P->freeSlots.size() : 0; }
+pp_planner* pp_pipeline_planner(pp_pipeline* P) { return P ? P->pl : nullptr; }
+
+int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* starts_dev, const double* goals_dev, const uint64_t* seeds_dev, uint64_t* tickets_out, int32_t* n_accepted)
+{
+	if (!P || n_queries < 0 || !n_accepted || (n_queries > 0 && (!starts_dev || !goals_dev || !seeds_dev))) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	*n_accepted = 0;
+	pp_planner* pl = P->pl;
+	PP_HIP_TRY(hipSetDevice(pl->map->ctx->device));
+	if (!pl->tableReady)
+		if (int rc = pp_planner_set_nonholo_table(pl, nullptr))
+			return rc;
+	int k = n_queries < (int)P->freeSlots.size() ? n_queries : (int)P->freeSlots.size();
+	if (k > (int)(P->slotListCap / 4))
+		k = (int)(P->slotListCap / 4);
+	if (k == 0)
+		return PP_OK;
+	// ---- slots and tickets
+	if (P->slotListPos + (size_t)k > P->slotListCap)
+		P->slotListPos = 0; // (a segment never wraps; segments in flight hold at most `capacity` of the 4 x capacity entries)
+	int32_t* const stage = P->slotStage + P->slotListPos;
+	int32_t* const listDev = P->slotLists + P->slotListPos;
+	P->slotListPos += (size_t)k;
+	for (int i = 0; i < k; i++) {
+		const int32_t s = P->freeSlots.back();
+		P->freeSlots.pop_back();
+		stage[i] = s;
+		P->slotState[(size_t)s] = 1;
+		const uint64_t ticket = P->nTickets++;
+		P->ticketOfSlot[(size_t)s] = ticket;
+		P->slotOfTicket[ticket] = s;
+		if (tickets_out)
+			tickets_out[i] = ticket;
+	}
+	// ---- inputs into their slots: on the control stream (never busy for long), so the caller's arrays are free when this returns
+	hipStream_t const w = P->wfStream[P->nextWf];
+	int32_t* const wctl = P->wfCtl[P->nextWf];
+	void* const wws = P->wfWorkspace[P->nextWf];
+	P->nextWf = (P->nextWf + 1) % kPipeWavefrontStreams;
+	PP_HIP_TRY(hipMemcpyAsync(listDev, stage, (size_t)k * 4, hipMemcpyHostToDevice, P->ctlStream));
+	hipLaunchKernelGGL(k_pipe_scatter, dim3((k + 255) / 256), dim3(256), 0, P->ctlStream, k, listDev, starts_dev, goals_dev, seeds_dev, pl->dStarts, pl->dGoals, pl->dSeeds);
+	PP_HIP_TRY(hipGetLastError());
+	PP_HIP_TRY(hipEventRecord(P->evIngest, P->ctlStream));
+	PP_HIP_TRY(hipStreamSynchronize(P->ctlStream));
+	// ---- ObstaclesHeuristic::Update for every goal (hybrid_a_star.cpp:249); each finished slot is appended to the ready ring
+	PP_HIP_TRY(hipStreamWaitEvent(w, P->evIngest, 0));
+	PP_HIP_TRY(hipMemsetAsync(wctl + 1, 0, 4, w)); // this launch's goal counter (the error flag at wctl[0] stays)
+	pl->args.m = pl->map->view();
+	pph::WavefrontPublish pub;
+	pub.slotList = listDev;
+	pub.readyTail = &P->ctl->readyTail;
+	pub.ready = P->ready;
+	pub.readyMask = P->readyMask;
+	PP_HIP_TRY(pph::launch_wavefront(w, pl->args.m, k, nullptr, pl->costFields, wws, pl->wfBytesPerSlot, pl->wfSlots, wctl, nullptr, /*tiledOut=*/true, /*goalPoses=*/pl->dGoals,
+		/*countersZeroed=*/true, nullptr, nullptr, nullptr, nullptr, pub));
+	P->nSubmitted += (unsigned long long)k;
+	*n_accepted = k;
+	return pipe_launch_search(P);
+}
+
+int pp_pipeline_submit(pp_pipeline* P, int32_t n_queries, const double* starts_host, const double* goals_host, const uint64_t* seeds_host, uint64_t* tickets_out, int32_t* n_accepted)
+{
+	if (!P || n_queries < 0 || !n_accepted || (n_queries > 0 && (!starts_host || !goals_host || !seeds_host))) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	*n_accepted = 0;
+	int k = n_queries < (int)P->freeSlots.size() ? n_queries : (int)P->freeSlots.size();
+	if (k == 0)
+		return PP_OK;
+	PP_HIP_TRY(hipSetDevice(P->pl->map->ctx->device));
+	double *ds = nullptr, *dg = nullptr;
+	uint64_t* dz = nullptr;
+	hipError_t e = hipMalloc((void**)&ds, (size_t)k * 24);
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&dg, (size_t)k * 24);
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&dz, (size_t)k * 8);
+	if (e == hipSuccess)
+		e = hipMemcpy(ds, starts_host, (size_t)k * 24, hipMemcpyHostToDevice);
+	if (e == hipSuccess)
+		e = hipMemcpy(dg, goals_host, (size_t)k * 24, hipMemcpyHostToDevice);
+	if (e == hipSuccess)
+		e = hipMemcpy(dz, seeds_host, (size_t)k * 8, hipMemcpyHostToDevice);
+	int rc = e == hipSuccess ? pp_pipeline_submit_dev(P, k, ds, dg, dz, tickets_out, n_accepted) : pph::hip_fail(e, "pp_pipeline_submit");
+	for (void* q : { (void*)ds, (void*)dg, (void*)dz })
+		if (q)
+			(void)hipFree(q);
+	return rc;
+}
+
+int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out, pp_query_result* results_out, int32_t release, int32_t* n_out)
+{
+	if (!P || max_results < 0 || !n_out || (max_results > 0 && (!tickets_out || !results_out))) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	*n_out = 0;
+	pp_planner* pl = P->pl;
+	int n = 0;
+	while (n < max_results) {
+		PipeDone* const rec = P->done + (P->doneHead & P->doneMask);
+		const unsigned long long stamp = __atomic_load_n(&rec->stamp, __ATOMIC_ACQUIRE);
+		if ((uint32_t)(stamp >> 32) != (uint32_t)(P->doneHead + 1ull))
+			break; // the next record has not been written yet
+		const int32_t slot = (int32_t)(uint32_t)stamp;
+		if (slot < 0 || slot >= P->capacity || P->slotState[(size_t)slot] != 1) {
+			set_error("pipeline completion ring corrupted");
+			return PP_ERR_HIP;
+		}
+		pl->hostResults[(size_t)slot] = rec->r;
+		tickets_out[n] = P->ticketOfSlot[(size_t)slot];
+		results_out[n] = rec->r.r;
+		if (release) {
+			P->slotOfTicket.erase(P->ticketOfSlot[(size_t)slot]);
+			P->slotState[(size_t)slot] = 0;
+			P->freeSlots.push_back(slot);
+		} else {
+			P->slotState[(size_t)slot] = 2;
+		}
+		P->doneHead++;
+		n++;
+	}
+	*n_out = n;
+	// the wavefront kernels' error flags come over asynchronously; what an earlier poll asked for is looked at now
+	if (P->errStage[0] || P->errStage[1]) {
+		set_error("obstacle-heuristic open list exceeded its workspace");
+		return PP_ERR_CAPACITY;
+	}
+	if (P->nSubmitted > P->doneHead) {
+		PP_HIP_TRY(hipSetDevice(pl->map->ctx->device));
+		for (int i = 0; i < kPipeWavefrontStreams; i++)
+			PP_HIP_TRY(hipMemcpyAsync(P->errStage + i, P->wfCtl[i], 4, hipMemcpyDeviceToHost, P->ctlStream));
+		// waves that left on their own (no work for idleTicks) are replaced while queries are outstanding
+		const auto now = std::chrono::steady_clock::now();
+		if (std::chrono::duration_cast<std::chrono::milliseconds>(now - P->lastLaunch).count() >= 20)
+			return pipe_launch_search(P);
+	}
+	return PP_OK;
+}
+
+int pp_pipeline_release(pp_pipeline* P, int32_t n, const uint64_t* tickets)
+{
+	if (!P || n < 0 || (n > 0 && !tickets)) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	for (int i = 0; i < n; i++) {
+		auto it = P->slotOfTicket.find(tickets[i]);
+		if (it == P->slotOfTicket.end() || P->slotState[(size_t)it->second] != 2) {
+			set_error("ticket is not a completed, held query");
+			return PP_ERR_INVALID;
+		}
+		P->slotState[(size_t)it->second] = 0;
+		P->freeSlots.push_back(it->second);
+		P->slotOfTicket.erase(it);
+	}
+	return PP_OK;
+}
+
+/// field slot of a completed query that is still held (polled with release = 0): the index the pp_planner_get_* accessors of
+/// pp_pipeline_planner() take
+int pp_pipeline_slot_of(pp_pipeline* P, uint64_t ticket)
+{
+	if (!P)
+		return -1;
+	auto it = P->slotOfTicket.find(ticket);
+	return it == P->slotOfTicket.end() || P->slotState[(size_t)it->second] != 2 ? -1 : it->second;
+}
+
+} // extern "C"

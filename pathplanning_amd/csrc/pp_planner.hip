@@ -1088,6 +1088,32 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	}
 }
 
+// ---- streaming pipeline (pp_pipeline.hpp): what the persistent search grid shares with the wavefront kernel and the host ----
+/// device memory, zeroed at creation
+struct PipeCtl {
+	unsigned long long readyTail;  // field slots appended to the ready ring by the wavefront kernel (absolute count)
+	unsigned long long readyHead;  // entries claimed by search rows
+	unsigned long long doneTail;   // completion records reserved
+	unsigned long long nSubmitted; // queries handed to the wavefront kernel so far (written by the host, in stream order before a top-up launch)
+	int stop;                      // host: leave as soon as the rows are idle
+	int pad[3];
+};
+/// completion record in PINNED HOST memory: the row writes the result, then the stamp ((position + 1) << 32 | slot); the host consumes
+/// records in position order as their stamps appear
+struct PipeDone {
+	unsigned long long stamp;
+	DevResult r;
+};
+struct PipeView {
+	PipeCtl* ctl = nullptr; // nullptr: the kernel works on a batch (no pipeline)
+	unsigned long long* ready = nullptr;
+	unsigned long long readyMask = 0;
+	PipeDone* done = nullptr;
+	unsigned long long doneMask = 0;
+	int* waveAlive = nullptr;         // [waves] 1 while a wave of some launch owns that wave index (and with it the rows' buffers)
+	unsigned long long idleTicks = 0; // loop passes (~4 us each: a sleep and three polls) a wave waits without work before it leaves on its own
+};
+
 #include "pp_planner_rows.hpp"
 #include "pp_postprocess.hpp"
 
@@ -1172,10 +1198,10 @@ int warm_up_kernels(pp_planner* p, pp_map* map)
 		SearchArgs none = p->args;
 		none.rowsWaves = 0; // every wave of the rows kernel leaves at once
 		none.listCap = 0;
-		hipLaunchKernelGGL(k_hybrid_search_rows, dim3(1), dim3(64 * PP_ROWS_WAVES_PER_WG), 0, s, none, 0, (const double*)nullptr, (const double*)nullptr, (const uint64_t*)nullptr,
+		hipLaunchKernelGGL(k_hybrid_search_rows<false>, dim3(1), dim3(64 * PP_ROWS_WAVES_PER_WG), 0, s, none, 0, (const double*)nullptr, (const double*)nullptr, (const uint64_t*)nullptr,
 			(const float*)nullptr, (Node*)nullptr, (HeapEntry*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (RsLogEntry*)nullptr, (PathRec*)nullptr, (unsigned long long*)nullptr,
 			(DevResult*)nullptr, (int*)nullptr, (SuspendRec*)nullptr, (const int32_t*)nullptr, 0, (const SuspendRec*)nullptr, (const int*)nullptr, (int*)nullptr, (int*)nullptr, 0,
-			(HeapEntry*)nullptr, 0.0, (uint8_t*)nullptr);
+			(HeapEntry*)nullptr, 0.0, (uint8_t*)nullptr, PipeView {});
 		e = hipGetLastError();
 	}
 	if (e == hipSuccess) {
@@ -1268,6 +1294,9 @@ void free_planner(pp_planner* p)
 
 } // namespace
 
+enum class PlannerUse { Batches, Pipeline, PipelineLogged };
+static int create_planner(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, int32_t search_rows, PlannerUse use, pp_planner** out);
+
 extern "C" {
 
 int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, pp_planner** out)
@@ -1277,6 +1306,14 @@ int pp_planner_create(pp_map* map, const pp_hybrid_params* params, int32_t max_b
 
 int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, int32_t search_rows, pp_planner** out)
 {
+	return create_planner(map, params, max_batch, max_nodes_per_query, search_rows, PlannerUse::Batches, out);
+}
+
+/// use: Batches = pp_planner_create_ex's planner; Pipeline / PipelineLogged = the buffer set of a streaming pipeline (pp_pipeline.hpp):
+/// max_batch field slots, always the rows kernel, no hand-over lists, the expansion log only when asked for (4 B x max_nodes per slot)
+static int create_planner(pp_map* map, const pp_hybrid_params* params, int32_t max_batch, int32_t max_nodes_per_query, int32_t search_rows, PlannerUse use, pp_planner** out)
+{
+	const bool forPipeline = use != PlannerUse::Batches;
 	if (!map || !params || !out || max_batch < 1 || max_nodes_per_query < 16 || search_rows < 0) {
 		set_error("invalid arguments");
 		return PP_ERR_INVALID;
@@ -1377,14 +1414,14 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		hipDeviceProp_t prop;
 		p->searchWaves = 2048;
 		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_hybrid_search_rows, 64 * PP_ROWS_WAVES_PER_WG, 0) == hipSuccess && perCu >= 1)
+			hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_hybrid_search_rows<false>, 64 * PP_ROWS_WAVES_PER_WG, 0) == hipSuccess && perCu >= 1)
 			p->searchWaves = perCu * PP_ROWS_WAVES_PER_WG * prop.multiProcessorCount;
 		// Which search kernel?  The four-queries-per-wave kernel (pp_planner_rows.hpp) issues ~4x fewer instructions per
 		// expansion and needs node/heap/key-map buffers only for its resident rows, so many batches fit in HBM at once;
 		// the one-query-per-wave kernel advances a single query ~1.4x faster.  Throughput-sized planners take the
 		// former, small ones (the plugin's single-query path) the latter.  PP_SEARCH_ROWS=0/1 forces either.
 		const char* env = getenv("PP_SEARCH_ROWS");
-		p->rowsKernel = env && (env[0] == '0' || env[0] == '1') ? env[0] == '1' : max_batch > 64;
+		p->rowsKernel = forPipeline || (env && (env[0] == '0' || env[0] == '1') ? env[0] == '1' : max_batch > 64);
 		// rows (= buffer slots) of the persistent grid: as many as can be resident, unless the caller shares the GPU
 		// between several planners (bench.py: resident rows / batches in flight)
 		int rows = p->searchWaves * kRowsPerWave;
@@ -1410,7 +1447,7 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 			const long x = strtol(v, nullptr, 10);
 			return (int)(x < lo ? lo : (x > hi ? hi : x));
 		};
-		A.suspendAfter = p->rowsKernel ? env_int("PP_SEARCH_SUSPEND_AFTER", 32768, 0, 1 << 30) : 0;
+		A.suspendAfter = p->rowsKernel && !forPipeline ? env_int("PP_SEARCH_SUSPEND_AFTER", 32768, 0, 1 << 30) : 0; // (a pipeline's rows keep their queries)
 		A.suspendAfter2 = env_int("PP_SEARCH_SUSPEND_AFTER2", 0, 0, 1 << 30);
 		A.extraSlots = A.suspendAfter > 0 ? env_int("PP_SEARCH_EXTRA_SLOTS", (max_batch + 15) / 16, 0, max_batch) : 0; // queries that may be set aside (the rest stays)
 		A.searchRows = p->searchRows;
@@ -1419,14 +1456,14 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 		// a wave (k_hybrid_search: ~11 us per expansion) than as one of four (rows kernel: 15-20 us).  The wavefront kernel
 		// already ranks the queries by probable length for the hand-out order; the first PP_SEARCH_DIRECT of that order get
 		// a wave of their own, in slots behind the spare ones.
-		p->directCount = p->rowsKernel ? env_int("PP_SEARCH_DIRECT", 0, 0, max_batch / 2) : 0;
+		p->directCount = p->rowsKernel && !forPipeline ? env_int("PP_SEARCH_DIRECT", 0, 0, max_batch / 2) : 0;
 		A.directCount = 0; // set per call (only when the order is available)
 		// compaction (pp_planner_rows.hpp): waves whose queue is empty and that have at most this many busy rows re-queue
 		// their queries for a second pass that packs them four per wave.  Off by default: it issues fewer instructions
 		// (a wave costs the same with one busy row as with four) but the passes of one batch run one after the other, and
 		// with eight batches in flight the longer per-batch latency costs more than the saved issue slots
 		// (measured: 8.1 k plans/s with PP_SEARCH_COMPACT=2 against 10.9 k without).
-		p->compactBelow = p->rowsKernel ? env_int("PP_SEARCH_COMPACT", 0, 0, kRowsPerWave) : 0;
+		p->compactBelow = p->rowsKernel && !forPipeline ? env_int("PP_SEARCH_COMPACT", 0, 0, kRowsPerWave) : 0;
 	}
 	hipError_t e = hipSuccess;
 	// Headroom.  The kernels this planner launches need scratch (private segment: k_hybrid_search_rows 408 B, k_wavefront
@@ -1457,13 +1494,14 @@ int pp_planner_create_ex(pp_map* map, const pp_hybrid_params* params, int32_t ma
 	alloc((void**)&p->bandMeta, S * (size_t)kBands);
 	alloc((void**)&p->heaps, S * N * sizeof(HeapEntry));
 	alloc((void**)&p->keymaps, S * A.ks.size() * 4);
-	alloc((void**)&p->expanded, B * N * 4);
+	if (use != PlannerUse::Pipeline) // (a pipeline keeps the expansion log only for parity tests: 4 B x max_nodes per field slot)
+		alloc((void**)&p->expanded, B * N * 4);
 	alloc((void**)&p->order, B * 4);
 	alloc((void**)&p->orderKeys, B * 4);
 	alloc((void**)&p->paths, B * (size_t)A.maxPath * sizeof(PathRec));
 	alloc((void**)&p->rsLogs, B * kRsLogCap * sizeof(RsLogEntry));
 	alloc((void**)&p->results, B * sizeof(DevResult));
-	alloc((void**)&p->prof, B * PH_COUNT * sizeof(unsigned long long));
+	alloc((void**)&p->prof, (forPipeline ? 1 : B) * PH_COUNT * sizeof(unsigned long long));
 	alloc((void**)&p->dStarts, B * 24);
 	alloc((void**)&p->dGoals, B * 24);
 	alloc((void**)&p->dSeeds, B * 8);
@@ -1646,9 +1684,9 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		const int cap1 = planner->args.suspendAfter, cap2 = planner->args.suspendAfter2, cpt = planner->compactBelow;
 		constexpr int kWg = PP_ROWS_WAVES_PER_WG;
 		planner->args.rowsWaves = grid;
-		hipLaunchKernelGGL(k_hybrid_search_rows, dim3((grid + kWg - 1) / kWg), dim3(64 * kWg), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
+		hipLaunchKernelGGL(k_hybrid_search_rows<false>, dim3((grid + kWg - 1) / kWg), dim3(64 * kWg), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev, planner->costFields, planner->nodes,
 			planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates, planner->results, ctl, list1,
-			ordered ? planner->order : nullptr, cap1, nullptr, nullptr, ctl + 1, spare, cpt, planner->bands, planner->bandInvW, planner->bandMeta);
+			ordered ? planner->order : nullptr, cap1, nullptr, nullptr, ctl + 1, spare, cpt, planner->bands, planner->bandInvW, planner->bandMeta, PipeView {});
 		PP_HIP_TRY(hipGetLastError());
 		const bool secondPass = cpt > 0 || (cap1 > 0 && cap2 > cap1);
 		if (secondPass) {
@@ -1656,10 +1694,10 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 			// busy row, and the one-query-per-wave kernel finishes those
 			const int waves2 = (planner->args.listCap + kRowsPerWave - 1) / kRowsPerWave;
 			planner->args.rowsWaves = waves2 < wavesMax ? waves2 : wavesMax;
-			hipLaunchKernelGGL(k_hybrid_search_rows, dim3((planner->args.rowsWaves + kWg - 1) / kWg), dim3(64 * kWg), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
+			hipLaunchKernelGGL(k_hybrid_search_rows<false>, dim3((planner->args.rowsWaves + kWg - 1) / kWg), dim3(64 * kWg), 0, s, planner->args, n_queries, starts_dev, goals_dev, seeds_dev,
 				planner->costFields, planner->nodes, planner->heaps, planner->keymaps, planner->expanded, planner->rsLogs, planner->paths, planner->mtStates,
 				planner->results, ctl + 2, list2, nullptr, cap2 > cap1 ? cap2 : 0, list1, ctl + 1, ctl + 3, spare, cpt > 0 ? 1 : 0, planner->bands, planner->bandInvW,
-				planner->bandMeta);
+				planner->bandMeta, PipeView {});
 			PP_HIP_TRY(hipGetLastError());
 		}
 		if ((secondPass || cap1 > 0) && dbgSkip != 3) // whatever is still set aside: one wave per query (the block count is read on the device)
@@ -1986,3 +2024,5 @@ int pp_planner_get_expanded(pp_planner* planner, int32_t q, int32_t* cells_host)
 }
 
 } // extern "C"
+
+#include "pp_pipeline.hpp"

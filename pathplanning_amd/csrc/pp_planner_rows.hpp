@@ -37,13 +37,14 @@ __device__ unsigned long long g_rowsStats[24];
 #endif
 
 // --------------------------------------------------------------------------------------------------- kernel --
+template <bool kPiped>
 __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_rows(SearchArgs A, int nQueries, const double* __restrict__ starts,
 	const double* __restrict__ goals, const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase,
 	HeapEntry* __restrict__ heapBase, uint32_t* __restrict__ keymapBase, uint32_t* __restrict__ expandedBase, RsLogEntry* __restrict__ rsLogBase,
 	PathRec* __restrict__ pathBase, unsigned long long* __restrict__ mtBase, DevResult* __restrict__ results, int* __restrict__ nextQuery,
 	SuspendRec* __restrict__ suspended, const int32_t* __restrict__ order, int suspendAfter, const SuspendRec* __restrict__ resumeList,
 	const int* __restrict__ nResumeDev, int* __restrict__ suspendedCount, int* __restrict__ spareCount, int compactBelow, HeapEntry* __restrict__ bandBase, double bandInvW,
-	uint8_t* __restrict__ bandMetaBase)
+	uint8_t* __restrict__ bandMetaBase, PipeView pipe)
 {
 	// Two uses.  (a) resumeList == nullptr: the rows take the batch's queries (nextQuery[0] counts them, order[] gives the
 	// hand-out order); a query that reaches `suspendAfter` expansions is written to suspended[] and its row continues in a
@@ -69,6 +70,20 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 	// search buffers (node records, heap, key map, engine state) belong to the ROW, not to the query: the row's
 	// queries use them one after the other, so a planner needs them for its resident rows only
 	// (a row that hands its query over to the one-query-per-wave kernel leaves the slot to it and takes a spare one)
+	// Third use (c), pipe.ctl != nullptr: the grid is the consumer of a streaming pipeline (pp_pipeline.hpp).  Rows take FIELD SLOTS from
+	// the ready ring the wavefront kernel appends to (`q` below is then the slot: start / goal / seed, field, path and log buffers are
+	// all indexed by it), announce results in a ring in host memory, and the wave leaves when nothing is left to claim; launches
+	// only top the grid up -- a wave whose index is still owned by a wave of an earlier launch leaves at once.
+	constexpr bool piped = kPiped; // (a separate instantiation: the batch form keeps its registers, the pipeline form drops the hand-over machinery)
+	if (piped) {
+		int owner = 0;
+		if (lane == 0)
+			owner = __hip_atomic_compare_exchange_strong(pipe.waveAlive + waveIdx, &owner, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : 1;
+		if (__builtin_amdgcn_readfirstlane(owner))
+			return;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the previous owner's last stores to the rows' buffers
+	}
+	int idleIters = 0; // (wave-uniform) consecutive loop passes with every row idle
 	size_t slot = (size_t)waveIdx * kRowsPerWave + (size_t)(lane >> 4);
 	Node* nodes = nodesBase + slot * A.maxNodes;
 	HeapEntry* heap = heapBase + slot * A.maxNodes;
@@ -311,7 +326,20 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			r.r.n_path_checks = pathChecks;
 			r.solutionNode = solutionNode;
 			r.nRsLog = nRsLog < kRsLogCap ? nRsLog : kRsLogCap;
-			results[q] = r;
+			if (!piped)
+				results[q] = r;
+			if (piped) {
+				// path records, logs and the record above reach memory (the host may fetch them once it has seen the announcement), then the
+				// completion record goes to the ring in host memory, its stamp last
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				const unsigned long long d = __hip_atomic_fetch_add(&pipe.ctl->doneTail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				PipeDone* const rec = pipe.done + (d & pipe.doneMask);
+				rec->r = r;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__hip_atomic_store(&rec->stamp, ((d + 1ull) << 32) | (unsigned long long)(uint32_t)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
 		}
 		act = false;
 	};
@@ -340,16 +368,39 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 	for (;;) {
 		// ================= rows without a query take the next one =================
 		if (!act && !done) {
-			int nq = 0;
-			if (rl == 0)
-				nq = atomicAdd(nextQuery, 1);
-			q = (int)row_read((uint32_t)nq, lane, 0);
-			if (!resumeList)
-				q += A.directCount; // the first entries of the hand-out order run one query per wave (k_hybrid_search)
-			const int nAvail = resumeList ? min(*nResumeDev, A.listCap) : nQueries;
-			if (q >= nAvail) {
-				done = true;
-			} else if (resumeList) {
+			bool none = false;
+			if (piped) {
+				// the ring's head entry, if it carries the stamp of its position (the wavefront kernel stores an entry after reserving its
+				// place, so the head may be reserved but not yet written: then there is nothing to take right now)
+				int got = -1;
+				if (rl == 0) {
+					// (one attempt per loop pass: a row that loses the race for the head entry tries again after its neighbours' next expansion)
+					unsigned long long h = __hip_atomic_load(&pipe.ctl->readyHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const unsigned long long e = __hip_atomic_load(pipe.ready + (h & pipe.readyMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((uint32_t)(e >> 32) == (uint32_t)(h + 1ull) &&
+						__hip_atomic_compare_exchange_strong(&pipe.ctl->readyHead, &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+						got = (int)(uint32_t)e;
+				}
+				q = (int)row_read((uint32_t)got, lane, 0);
+				none = q < 0;
+				if (!none) {
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the field, and the slot's start / goal / seed
+				}
+			} else {
+				int nq = 0;
+				if (rl == 0)
+					nq = atomicAdd(nextQuery, 1);
+				q = (int)row_read((uint32_t)nq, lane, 0);
+				if (!resumeList)
+					q += A.directCount; // the first entries of the hand-out order run one query per wave (k_hybrid_search)
+				const int nAvail = resumeList ? min(*nResumeDev, A.listCap) : nQueries;
+				if (q >= nAvail) {
+					done = true;
+					none = true;
+				}
+			}
+			if (none) {
+			} else if (!piped && resumeList) {
 				// ---- continue a suspended query where it stopped, in the slot that holds its nodes / heap / key map / engine
 				const SuspendRec rec = resumeList[q];
 				q = rec.q;
@@ -498,10 +549,43 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			statIter[__popcll(actMask) / kRowLanes]++;
 #endif
 		ROWS_STAMP(0) // taking queries
-		if (!actMask)
-			break; // every row has run out of queries
+		if (!actMask) {
+			if (!piped)
+				break; // every row has run out of queries
+			// ---- pipeline: every row is idle.  Leave when the host says so, when every submitted query has been claimed (a later
+			// submission brings its own launch), or after idleTicks without work (a safety net: no wave waits for ever on a producer
+			// that cannot run); else wait a little and look at the ring again.
+			int leave = 0;
+			if (lane == 0) {
+				const unsigned long long sub = __hip_atomic_load(&pipe.ctl->nSubmitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const unsigned long long head = __hip_atomic_load(&pipe.ctl->readyHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const int stop = __hip_atomic_load(&pipe.ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const bool timedOut = (unsigned long long)idleIters > pipe.idleTicks;
+				if (stop || head >= sub || timedOut) {
+					// the wave index goes back first, THEN the submission count is read again: a top-up launch that found this index
+					// still owned was started after its submission count was written, so one of the two sees the other
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					const int was = __hip_atomic_exchange(pipe.waveAlive + waveIdx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					leave = 1 + (was & 0); // (the exchange's result is consumed: it has completed before the loads below are issued)
+					const unsigned long long sub2 = __hip_atomic_load(&pipe.ctl->nSubmitted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const unsigned long long head2 = __hip_atomic_load(&pipe.ctl->readyHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (!stop && !timedOut && head2 < sub2) {
+						int expect = 0;
+						if (__hip_atomic_compare_exchange_strong(pipe.waveAlive + waveIdx, &expect, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+							leave = 0; // new work arrived in between and nobody took the index: carry on
+					}
+				}
+			}
+			if (__builtin_amdgcn_readfirstlane(leave))
+				break;
+			idleIters++;
+			__builtin_amdgcn_s_sleep(64);
+			continue;
+		}
+		idleIters = 0;
 		// compaction trigger (all lanes vote): some row found the queue empty and few rows of the wave are still busy
-		const bool compact = compactBelow > 0 && __ballot(done) != 0ull && __popcll(actMask) <= compactBelow * kRowLanes;
+		const bool compact = !piped && compactBelow > 0 && __ballot(done) != 0ull && __popcll(actMask) <= compactBelow * kRowLanes;
 		if (!act)
 			continue;
 
@@ -516,7 +600,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		// slot); (b) compaction: the queue is empty and at most `compactBelow` rows of this wave are still busy -- a wave
 		// costs the same with one busy row as with four, so the leftovers of all such waves are re-packed four per wave
 		// by the next stage and this wave ends.
-		const bool capHit = suspendAfter > 0 && nExpanded >= suspendAfter && !noSuspend;
+		const bool capHit = !piped && suspendAfter > 0 && nExpanded >= suspendAfter && !noSuspend;
 		if (capHit || compact) {
 			bool ok = true;
 			int sp = 0;
@@ -658,7 +742,8 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		if (rl == 0) {
 			if (pKey != kNoKey)
 				keymap[pKey] = kExplored; // children in the parent's own cell are caught by a key compare below
-			(expandedBase + (size_t)q * maxNodes)[nExpanded] = pKey; // packed discrete pose of the expanded node
+			if (!piped || expandedBase) // (a pipeline keeps the log only when asked to)
+				(expandedBase + (size_t)q * maxNodes)[nExpanded] = pKey; // packed discrete pose of the expanded node
 		}
 		rsNode = -1;
 		nExpanded++;

@@ -509,7 +509,8 @@ __device__ __forceinline__ void rank_sort_masks(uint64_t* skey, uint32_t* hist, 
 template <bool kProfile>
 __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapView m, int nGoals, const int32_t* __restrict__ goalCells, float* __restrict__ costOut,
 	void* workspace, int64_t bytesPerSlot, uint32_t fcap, uint32_t gcap, int32_t* errorFlag, unsigned long long* __restrict__ prof, int* __restrict__ goalCounter,
-	int tiledOut, const double* __restrict__ goalPoses, const double* __restrict__ orderStarts, int32_t* __restrict__ orderOut, int* __restrict__ doneCounter, float* __restrict__ orderKeys)
+	int tiledOut, const double* __restrict__ goalPoses, const double* __restrict__ orderStarts, int32_t* __restrict__ orderOut, int* __restrict__ doneCounter, float* __restrict__ orderKeys,
+	pph::WavefrontPublish pub)
 {
 	unsigned long long ph[WP_COUNT];
 	unsigned long long tl = 0;
@@ -561,14 +562,30 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		hist[i] = 0u;
 	int tagGoal = -1; // goal whose fallback rounds the tag grid currently describes (it is cleared lazily)
 	// goals are handed out dynamically: a workgroup that finishes early takes the next one (balanced tail)
+	int pendingSlot = -1; // pipeline use: field slot of the goal this workgroup has just finished, not yet announced
 	for (;;) {
-		__syncthreads();
-		if (tid == 0)
+		__syncthreads(); // (every wave's stores of the previous goal have completed: the barrier's release waits for them)
+		if (tid == 0) {
+			if (pendingSlot >= 0) {
+				// the finished field is handed to the search grid (pp_pipeline.hpp): this XCD's dirty lines written back, then the
+				// slot number appended to the ready ring under the stamp of its position (consumers take an entry only when its stamp
+				// matches, so entries may land out of order)
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				const unsigned long long t = __hip_atomic_fetch_add(pub.readyTail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(pub.ready + (t & pub.readyMask), ((t + 1ull) << 32) | (unsigned long long)(uint32_t)pendingSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
 			s_goal = atomicAdd(goalCounter, 1);
+		}
+		pendingSlot = -1;
 		__syncthreads();
-		const int g = s_goal;
-		if (g >= nGoals)
+		const int gi = s_goal;
+		if (gi >= nGoals)
 			break;
+		// g indexes the goal poses and the output fields: the launch's own numbering, or (pipeline) the field slot of entry gi
+		const int g = pub.slotList ? pub.slotList[gi] : gi;
+		if (pub.ready)
+			pendingSlot = g;
 		if (kProfile) {
 			for (int i = 0; i < WP_COUNT; i++)
 				ph[i] = 0;
@@ -1218,13 +1235,13 @@ hipError_t warm_up_wavefront(hipStream_t s, const MapView& m, int32_t* ctlDev)
 {
 	// nGoals = 0: the workgroup reads the goal counter, finds nothing to do and leaves; no other pointer is dereferenced
 	hipLaunchKernelGGL(k_wavefront<false>, dim3(1), dim3(WF_T), 0, s, m, 0, nullptr, nullptr, nullptr, (int64_t)0, 0u, 0u, ctlDev, nullptr, (int*)(ctlDev + 1), 0, nullptr, nullptr,
-		nullptr, nullptr, nullptr);
+		nullptr, nullptr, nullptr, WavefrontPublish {});
 	return hipGetLastError();
 }
 
 hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
 	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev, bool tiledOut, const double* goalPosesDev, bool countersZeroed,
-	const double* orderStartsDev, int32_t* orderOutDev, int* doneCounterDev, float* orderKeysDev)
+	const double* orderStartsDev, int32_t* orderOutDev, int* doneCounterDev, float* orderKeysDev, const WavefrontPublish& pub)
 {
 	if (nGoals > WF_LCAP)
 		orderOutDev = nullptr; // the epilogue sorts in the LDS sort buffer
@@ -1241,10 +1258,10 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 	}
 	if (profDev)
 		hipLaunchKernelGGL(k_wavefront<true>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev);
+			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev, pub);
 	else
 		hipLaunchKernelGGL(k_wavefront<false>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev);
+			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev, pub);
 	return hipGetLastError();
 }
 

@@ -615,6 +615,117 @@ class HybridAStarBatch:
             pass
 
 
+class HybridAStarPipeline:
+    """Streaming form of the batched planner (include/pp_hip.h: pp_pipeline_*): queries are submitted as they come, every goal's
+    obstacle-heuristic field is handed by the wavefront kernel to ONE persistent search grid through a device-side queue, results are
+    polled in completion order and their field slots recycled.  Per-query results are those of HybridAStarBatch.search_batch."""
+
+    def __init__(self, validator, params=None, capacity=4096, max_nodes=81920, search_rows=0, log_expansions=False):
+        self.validator = validator
+        self.map = validator.map
+        self.lib = self.map.lib
+        self.params = params if params is not None else HybridAStarSearchParameters()
+        self.cparams = self.params.to_c()
+        h = C.c_void_p()
+        check(self.lib.pp_pipeline_create(self.map.h, C.byref(self.cparams), int(capacity), int(max_nodes), int(search_rows), int(bool(log_expansions)), C.byref(h)))
+        self.h = h
+        self.planner_h = C.c_void_p(self.lib.pp_pipeline_planner(self.h))
+        self.capacity = self.lib.pp_pipeline_capacity(self.h)
+        self.search_rows = self.lib.pp_pipeline_search_rows(self.h)
+        self.num_primitives = self.lib.pp_planner_num_primitives(self.planner_h)
+        self._held = {}  # ticket -> QueryResult of completed queries polled with release=False
+
+    def initialize(self, nonholo_table=None):
+        t = None if nonholo_table is None else np.ascontiguousarray(nonholo_table, dtype=np.float64)
+        check(self.lib.pp_planner_set_nonholo_table(self.planner_h, ptr(t) if t is not None else None))
+        return True
+
+    def nonholo_table(self):
+        cp = self.cparams
+        dims = np.zeros(3, dtype=np.int32)
+        offs = np.zeros(2)
+        lo, up = np.ascontiguousarray(self.map.lower), np.ascontiguousarray(self.map.upper)
+        check(self.lib.pp_nonholo_dims(ptr(lo), ptr(up), C.byref(cp), ptr(dims), ptr(offs)))
+        t = np.empty(tuple(int(x) for x in dims))
+        check(self.lib.pp_planner_get_nonholo_table(self.planner_h, ptr(t)))
+        return t
+
+    def submit(self, starts, goals, seeds):
+        """Returns the tickets of the queries taken (a prefix of the input: as many as there were free slots)."""
+        s, g = _f64(starts, 3), _f64(goals, 3)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64)
+        n = len(s)
+        tickets = np.empty(n, dtype=np.uint64)
+        k = C.c_int32(0)
+        check(self.lib.pp_pipeline_submit(self.h, n, ptr(s), ptr(g), ptr(sd), ptr(tickets), C.byref(k)))
+        return tickets[:k.value]
+
+    def submit_dev(self, starts_t, goals_t, seeds_t, n=None, offset=0):
+        """device tensors ([n, 3] f64, [n, 3] f64, [n] int64 / uint64); returns (first ticket, number taken)"""
+        n = starts_t.numel() // 3 - offset if n is None else n
+        tickets = np.empty(max(n, 1), dtype=np.uint64)
+        k = C.c_int32(0)
+        check(self.lib.pp_pipeline_submit_dev(self.h, n, C.c_void_p(starts_t.data_ptr() + 24 * offset), C.c_void_p(goals_t.data_ptr() + 24 * offset),
+                                              C.c_void_p(seeds_t.data_ptr() + 8 * offset), ptr(tickets), C.byref(k)))
+        return (int(tickets[0]) if k.value else -1), k.value
+
+    def poll(self, max_results=4096, release=True):
+        """Completed queries so far: (tickets [k] uint64, results [k] QueryResult); never blocks."""
+        tickets = np.empty(max_results, dtype=np.uint64)
+        res = (QueryResult * max_results)()
+        k = C.c_int32(0)
+        check(self.lib.pp_pipeline_poll(self.h, int(max_results), ptr(tickets), C.cast(res, C.c_void_p), int(bool(release)), C.byref(k)))
+        if not release:
+            for i in range(k.value):
+                self._held[int(tickets[i])] = res[i]
+        return tickets[:k.value], res
+
+    def in_flight(self):
+        return self.lib.pp_pipeline_in_flight(self.h)
+
+    def free_slots(self):
+        return self.lib.pp_pipeline_free_slots(self.h)
+
+    def release(self, tickets):
+        t = np.ascontiguousarray(tickets, dtype=np.uint64)
+        check(self.lib.pp_pipeline_release(self.h, len(t), ptr(t)))
+        for x in t:
+            self._held.pop(int(x), None)
+
+    def get_path_of(self, ticket):
+        """solution path of a completed query polled with release=False"""
+        slot = self.lib.pp_pipeline_slot_of(self.h, C.c_uint64(int(ticket)))
+        if slot < 0:
+            raise ValueError("ticket is not a completed, held query")
+        n = self._held[int(ticket)].n_path
+        poses, kind, prim, length, tuv = np.empty((n, 3)), np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32), np.empty(n), np.empty((n, 3))
+        if n:
+            check(self.lib.pp_planner_get_path(self.planner_h, slot, ptr(poses), ptr(kind), ptr(prim), ptr(length), ptr(tuv)))
+        return dict(poses=poses, kind=kind, prim=prim, length=length, tuv=tuv)
+
+    def get_expanded_of(self, ticket):
+        """expansion sequence (log_expansions=True) of a completed query polled with release=False"""
+        slot = self.lib.pp_pipeline_slot_of(self.h, C.c_uint64(int(ticket)))
+        if slot < 0:
+            raise ValueError("ticket is not a completed, held query")
+        n = self._held[int(ticket)].n_expanded
+        cells = np.empty((n, 3), dtype=np.int32)
+        if n:
+            check(self.lib.pp_planner_get_expanded(self.planner_h, slot, ptr(cells)))
+        return cells
+
+    def close(self):
+        if self.h:
+            self.lib.pp_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _RRTBase:
     """RRT / RRTStar over R2 (algo/rrt.h, algo/rrt_star.h): the whole sequential loop runs on the device.
     validator=None reproduces StateValidatorFree (planner/tests/test_rrt*.cpp)."""

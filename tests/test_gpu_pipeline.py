@@ -1,0 +1,119 @@
+"""-m gpu: the streaming pipeline (include/pp_hip.h: pp_pipeline_*; pathplanning_amd/csrc/pp_pipeline.hpp) against the CPU oracle and
+against the batch planner: every query's status, expansion sequence, counters, cost and path are what pp_planner_search_batch
+returns -- with field slots recycled several times (a stale cache line of a slot's previous field, start or goal would show here),
+across submissions that arrive while the grid is busy, and after the grid has gone idle and been started again."""
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_common import make_pair, valid_random_poses
+
+pytestmark = pytest.mark.gpu
+
+
+def drain(pipe, want, release=True, timeout=120.0):
+    """polls until `want` results have arrived; returns {ticket: QueryResult}"""
+    got = {}
+    t0 = time.time()
+    while len(got) < want:
+        tickets, res = pipe.poll(4096, release=release)
+        for i, t in enumerate(tickets):
+            got[int(t)] = res[i]
+        if not len(tickets):
+            time.sleep(0.001)
+        assert time.time() - t0 < timeout, "pipeline stalled: %d of %d results" % (len(got), want)
+    return got
+
+
+def check_against_oracle(pipe, ticket, r, h, start, goal, seed):
+    o = h.search(start, goal, int(seed))
+    assert r.status == o["status"], (ticket, r.status, o["status"])
+    assert r.n_expanded == len(o["expanded"]) and r.n_nodes == o["n_nodes"]
+    assert np.array_equal(pipe.get_expanded_of(ticket), o["expanded"])
+    assert r.n_rng_draws == o["n_rng_draws"] and r.n_rs_attempts == o["n_rs_attempts"]
+    assert r.n_state_checks == o["n_state_checks"] and r.n_path_checks == o["n_path_checks"]
+    if o["status"] == 0:
+        assert abs(r.cost - o["cost"]) < 1e-5
+        path = pipe.get_path_of(ticket)
+        assert len(path["poses"]) == len(o["path_poses"]) and np.abs(path["poses"] - o["path_poses"]).max() < 1e-5
+        assert np.array_equal(path["kind"], o["path_kind"])
+    return o["status"] == 0
+
+
+def test_pipeline_matches_the_oracle_with_recycled_slots():
+    import pathplanning_amd as pa
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    rng = np.random.RandomState(11)
+    n = 200
+    starts, goals = valid_random_poses(rng, w, n), valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 1000
+    pipe = pa.HybridAStarPipeline(val, capacity=48, max_nodes=32768, search_rows=16, log_expansions=True)
+    assert pipe.capacity == 48 and pipe.search_rows == 16
+    pipe.initialize()
+    h = O.Hybrid(w, O.params_array(), table=pipe.nonholo_table())
+    index_of = {}
+    nxt, done, solved = 0, 0, 0
+    t0 = time.time()
+    while done < n:
+        if nxt < n and pipe.free_slots() > 0:
+            k = min(n - nxt, 17)  # odd-sized submissions, most of them while the grid is busy
+            tickets = pipe.submit(starts[nxt:nxt + k], goals[nxt:nxt + k], seeds[nxt:nxt + k])
+            for i, t in enumerate(tickets):
+                index_of[int(t)] = nxt + i
+            nxt += len(tickets)
+        tickets, res = pipe.poll(64, release=False)
+        for i, t in enumerate(tickets):
+            q = index_of[int(t)]
+            solved += check_against_oracle(pipe, int(t), res[i], h, starts[q], goals[q], seeds[q])
+            done += 1
+        if len(tickets):
+            pipe.release(tickets)
+        assert time.time() - t0 < 300
+    assert nxt == n and pipe.in_flight() == 0 and pipe.free_slots() == 48
+    assert solved >= n // 2
+    pipe.close()
+
+
+def test_pipeline_equals_the_batch_planner_and_restarts_after_idling():
+    import pathplanning_amd as pa
+    w, ms, val, ctx = make_pair(512, 12, 1)
+    rng = np.random.RandomState(5)
+    n = 1500
+    starts, goals = valid_random_poses(rng, w, n), valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 7
+    batch = pa.HybridAStarBatch(val, max_batch=n, max_nodes=65536, search_rows=256)
+    batch.initialize()
+    want = batch.search_batch(starts, goals, seeds)
+    table = batch.nonholo_table()
+    pipe = pa.HybridAStarPipeline(val, capacity=400, max_nodes=65536, search_rows=128)
+    pipe.initialize(table)
+    fields = ("status", "n_expanded", "n_nodes", "n_path", "n_rng_draws", "n_rs_attempts", "n_state_checks", "n_path_checks", "n_lattice_boundary_hits")
+
+    def run(lo, hi):
+        index_of, nxt, got = {}, lo, {}
+        t0 = time.time()
+        while len(got) < hi - lo:
+            if nxt < hi and pipe.free_slots() > 0:
+                tickets = pipe.submit(starts[nxt:hi], goals[nxt:hi], seeds[nxt:hi])
+                for i, t in enumerate(tickets):
+                    index_of[int(t)] = nxt + i
+                nxt += len(tickets)
+            tickets, res = pipe.poll(512)
+            for i, t in enumerate(tickets):
+                got[index_of[int(t)]] = res[i]
+            if not len(tickets):
+                time.sleep(0.0005)
+            assert time.time() - t0 < 300
+        for q, r in got.items():
+            for f in fields:
+                assert getattr(r, f) == getattr(want[q], f), (q, f, getattr(r, f), getattr(want[q], f))
+            assert r.cost == want[q].cost or r.status != 0
+
+    run(0, 1000)
+    assert pipe.in_flight() == 0
+    time.sleep(0.3)  # every wave of the grid has left by now (nothing submitted is unclaimed): the next submission starts it again
+    run(1000, n)
+    pipe.close()
+    batch.close()
