@@ -55,7 +55,13 @@ def main():
                     help="delay between the first launches of the lanes; < 0 (default): the wavefront time of one batch alone, measured in the warm-up; 0: all lanes start together")
     ap.add_argument("--chain", choices=["none", "first", "always"], default="none",
                     help="pp_planner_start_after_fields_of between consecutively launched lanes (event-based phasing): in the first round of launches / always / never")
-    ap.add_argument("--streams", type=int, default=8, help="independent batches kept in flight (one planner + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=8, help="--mode lanes: independent batches kept in flight (one planner + HIP stream each)")
+    ap.add_argument("--mode", choices=("pipeline", "lanes"), default="pipeline",
+                    help="pipeline (default): the library's streaming pipeline (pp_pipeline_*): one persistent search grid fed by the wavefront kernel through a "
+                         "device-side queue, field slots recycled; lanes: round 2's scheduling, --streams batch planners refilled by this script")
+    ap.add_argument("--capacity", type=int, default=0, help="--mode pipeline: queries in flight (field slots); 0 = 6 steps' worth")
+    ap.add_argument("--pipe-rows", type=int, default=2304, help="--mode pipeline: rows of the persistent search grid")
+    ap.add_argument("--submit-chunk", type=int, default=2048, help="--mode pipeline: queries per submission (= per wavefront launch)")
     args = ap.parse_args()
 
     import numpy as np
@@ -92,9 +98,23 @@ def main():
     B = args.batch if args.scaling == "weak" else len(sharding.shard_indices(args.batch, rank, max(world, 1)))
     # Batches are independent, and one batch alone cannot fill the GPU (its search kernel is bound by the longest
     # query): keep `streams` batches in flight, each on its own HIP stream with its own planner workspace.
-    n_streams = max(1, args.streams)
+    pipeline_mode = args.mode == "pipeline"
+    n_streams = 1 if pipeline_mode else max(1, args.streams)
     lanes = []
-    for si in range(n_streams):
+    pipe = None
+    if pipeline_mode:
+        c = pa.Context(local_rank)
+        ms_i, val_i = synthetic.upload(c, m)
+        cap = args.capacity if args.capacity > 0 else 6 * B
+        pipe = pa.HybridAStarPipeline(val_i, params, capacity=cap, max_nodes=args.max_nodes, search_rows=args.pipe_rows)
+        pipe.initialize()  # non-holonomic table built on the device
+
+        class _PipeAsPlanner:  # what the reporting below reads from lanes[0][3]
+            num_primitives = pipe.num_primitives
+            search_rows = pipe.search_rows
+            nonholo_table = staticmethod(pipe.nonholo_table)
+        lanes.append((c, ms_i, val_i, _PipeAsPlanner))
+    for si in range(0 if pipeline_mode else n_streams):
         c = pa.Context(local_rank)
         ms_i, val_i = synthetic.upload(c, m)
         # the batches in flight share the GPU: each planner gets its share of the resident search rows (8 waves x 4 rows per CU)
@@ -131,9 +151,9 @@ def main():
         # One launch per run rather than per step: a collective's kernel queues behind the persistent search grids like
         # any other launch.
         if world > 1 and step_records:
-            k = len(step_records)
-            rec = np.concatenate(step_records)  # [k * B, fields], step-major
-            rec = rec.reshape(k, B, -1).transpose(1, 0, 2).reshape(B, -1)  # one row per local query, k records wide
+            rec = np.concatenate(step_records)  # [k * B, fields] (lanes: step-major; pipeline: completion order)
+            k = len(rec) // B
+            rec = rec.reshape(k, B, -1).transpose(1, 0, 2).reshape(B, -1)  # one row per local query slot, k records wide
             out = sharding.gather_records(rec, total_queries, rank, world, device=dev)
             step_records.clear()
             return out
@@ -176,6 +196,42 @@ def main():
         gather_all()
         return out, timings
 
+    def run_steps_pipeline(k):
+        """k steps = k x B queries through the library's pipeline: submitted as slots are free, polled in completion order.  Returns the
+        last step's results (by query index) and the sums over all k steps."""
+        from pathplanning_amd._lib import QUERY_RESULT_DTYPE
+        total, submitted, done = k * B, 0, 0
+        last = np.zeros(B, dtype=QUERY_RESULT_DTYPE)
+        sums = dict(success=0, expansions=0, rs_attempts=0, rng_draws=0, state_checks=0, path_checks=0)
+        base = None
+        while done < total:
+            if submitted < total:
+                free = pipe.free_slots()
+                off = submitted % B
+                want = min(B - off, args.submit_chunk)
+                if free >= want:  # a submission is one wavefront launch: never a handful of goals (a launch lasts at least one goal's 20 ms)
+                    first, kk = pipe.submit_dev(d_starts, d_goals, d_seeds, n=want, offset=off)
+                    if base is None:
+                        base = first
+                    submitted += kk
+            tickets, res = pipe.poll_array(8192)
+            if len(tickets):
+                idx = (tickets - np.uint64(base)).astype(np.int64)
+                in_last = idx >= (k - 1) * B
+                last[idx[in_last] - (k - 1) * B] = res[in_last]
+                sums["success"] += int((res["status"] == 0).sum())
+                sums["expansions"] += int(res["n_expanded"].sum())
+                sums["rs_attempts"] += int(res["n_rs_attempts"].sum())
+                sums["rng_draws"] += int(res["n_rng_draws"].sum())
+                sums["state_checks"] += int(res["n_state_checks"].sum())
+                sums["path_checks"] += int(res["n_path_checks"].sum())
+                done += len(tickets)
+                if world > 1:
+                    step_records.append(np.column_stack([res["status"].astype(np.float64), res["cost"], res["n_expanded"].astype(np.float64), res["n_path"].astype(np.float64)]))
+            else:
+                time.sleep(0.0002)
+        return last, sums
+
     def sync_all():
         if world > 1:
             dist.barrier()
@@ -188,26 +244,47 @@ def main():
     # queries with the GPU nearly empty, every cycle.  Started one wavefront apart their phases interleave from the first cycle on
     # (measured with the driver's --steps 20 --warmup 5: 13.2 k plans/s together, 14.5 k staggered; 150-200 ms all within 3 %).
     # The delay is measured, not assumed: the first warm-up batch runs alone and its wavefront time is the stagger.
-    if args.stagger_ms < 0:
+    pipe_kernel = None
+    if pipeline_mode:
+        # the pipeline has no lanes to warm one by one: the warm-up steps touch every field slot once (capacity = 6 steps' worth)
+        warm = max(args.warmup, 1)
+        run_steps_pipeline(warm)
+        sync_all()
+        pipe.timings()  # reset
+    elif args.stagger_ms < 0:
         run_steps(1)
         sync_all()
         stagger_ms[0] = float(lanes[0][3].last_timings()[0])
     else:
         stagger_ms[0] = args.stagger_ms
-    warm = max(args.warmup, n_streams)
-    run_steps(warm)
-    sync_all()
+    if not pipeline_mode:
+        warm = max(args.warmup, n_streams)
+        run_steps(warm)
+        sync_all()
     if args.debug_skip:
         if "PP_HIP_LIB" not in os.environ:
             raise SystemExit("--debug-skip needs a diagnostic build of the library: python tools/build_variant.py skip -DPP_ENABLE_DEBUG_SKIP=1, "
                              "then PP_HIP_LIB=pathplanning_amd/lib/variants/skip.so (the shipped library has no work-skipping path)")
         os.environ["PP_DEBUG_SKIP"] = str(args.debug_skip)
     t0 = time.perf_counter()
-    res, timings = run_steps(args.steps)
+    if pipeline_mode:
+        res, run_sums = run_steps_pipeline(args.steps)
+        gather_all()
+    else:
+        res, timings = run_steps(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
-    wf_ms = [t[0] for t in timings]
-    se_ms = [t[1] for t in timings]
+    if pipeline_mode:
+        res = res.view(np.recarray)
+        pipe_kernel = pipe.timings()
+        # wavefront: one launch per submission, timed by HIP events on its stream.  Search grid: ONE persistent grid that is alive from
+        # the first submission to the last result -- its "launch" is the timed region itself (the launches that only top up a full
+        # grid last microseconds and say nothing); what it processed in that time is the whole run's expansions.
+        wf_ms = [pipe_kernel["wavefront_ms_total"] / max(1, pipe_kernel["wavefront_launches"])]
+        se_ms = [elapsed * 1e3]
+    else:
+        wf_ms = [t[0] for t in timings]
+        se_ms = [t[1] for t in timings]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -257,19 +334,40 @@ def main():
     wf = float(np.mean(wf_ms))
     se = float(np.mean(se_ms))
     cells = ms.rows * ms.cols
-    wf_gbs = B * cells * WAVEFRONT_BYTES_PER_CELL / (wf * 1e-3) / 1e9
-    se_gbs = n_children * CHILD_BYTES / (se * 1e-3) / 1e9
-    if wf >= se:
-        roof = dict(kernel="k_wavefront", bound="hbm", achieved=wf_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=wf_gbs / HBM_PEAK_GBS, traffic=None,
-                    ms_per_launch=wf, algorithmic_bytes_per_launch=B * cells * WAVEFRONT_BYTES_PER_CELL)
+    if pipeline_mode:
+        # per launch: the goals of an average wavefront launch; the search grid's one "launch" processed every expansion of the run
+        wf_goals = pipe_kernel["wavefront_goals"] / max(1, pipe_kernel["wavefront_launches"])
+        wf_bytes = wf_goals * cells * WAVEFRONT_BYTES_PER_CELL
+        se_bytes = run_sums["expansions"] * planner.num_primitives * CHILD_BYTES
+        search_kernel = "k_hybrid_search_rows<true> (persistent grid)"
     else:
-        roof = dict(kernel=search_kernel, bound="hbm", achieved=se_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=se_gbs / HBM_PEAK_GBS, traffic=None,
-                    ms_per_launch=se, algorithmic_bytes_per_launch=n_children * CHILD_BYTES)
+        wf_bytes = B * cells * WAVEFRONT_BYTES_PER_CELL
+        se_bytes = n_children * CHILD_BYTES
+    wf_gbs = wf_bytes / (wf * 1e-3) / 1e9
+    se_gbs = se_bytes / (se * 1e-3) / 1e9
+    # one roofline entry per kernel, each with ITS OWN time; `roofline` is the one that is busy longest per step
+    roofs = {
+        "k_wavefront": dict(kernel="k_wavefront", bound="hbm", achieved=wf_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=wf_gbs / HBM_PEAK_GBS, traffic=None,
+                            ms_per_launch=wf, algorithmic_bytes_per_launch=wf_bytes),
+        "search": dict(kernel=search_kernel, bound="hbm", achieved=se_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=se_gbs / HBM_PEAK_GBS, traffic=None,
+                       ms_per_launch=se, algorithmic_bytes_per_launch=se_bytes),
+    }
+    if pipeline_mode:
+        # both kernels are busy for the whole timed region; the wavefront kernel's launches cover it several times over (two streams):
+        # the dominant one is the one with more busy time per step
+        wf_busy_per_step = pipe_kernel["wavefront_ms_total"] / args.steps
+        roofs["k_wavefront"]["busy_ms_per_step"] = wf_busy_per_step
+        roofs["search"]["busy_ms_per_step"] = elapsed * 1e3 / args.steps
+        roof = roofs["k_wavefront"] if wf_busy_per_step >= elapsed * 1e3 / args.steps else roofs["search"]
+    else:
+        roof = roofs["k_wavefront"] if wf >= se else roofs["search"]
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     # the committed PMC passes were made on the default workload: for any other map / batch the counter figure does not apply
     if os.path.exists(tj) and (args.cells, args.batch, args.obstacles) == (1024, 4096, 24):
         try:
-            roof["traffic"] = json.load(open(tj)).get(roof["kernel"])
+            tr = json.load(open(tj))
+            for r_ in roofs.values():
+                r_["traffic"] = tr.get(r_["kernel"].split("<")[0].split(" ")[0])
         except Exception:
             pass
 
@@ -321,7 +419,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "Hybrid A* batch of %d start/goal pairs per GPU per step on one %dx%d map (res 0.1 m, %d rectangle outlines), P=%d constant-steer primitives + RS analytic expansion, exact-order obstacle heuristic per query" % (B, args.cells, args.cells, args.obstacles, planner.num_primitives),
-                       "queries_per_gpu": B, "grid": [ms.rows, ms.cols], "parallelism": "query-sharded x%d" % n_gpus, "batches_in_flight": n_streams, "lane_stagger_ms": round(stagger_ms[0], 1)},
+                       "queries_per_gpu": B, "grid": [ms.rows, ms.cols], "parallelism": "query-sharded x%d" % n_gpus,
+                       **({"scheduler": "library pipeline (pp_pipeline_*)", "queries_in_flight": pipe.capacity, "search_rows": pipe.search_rows} if pipeline_mode
+                          else {"scheduler": "bench.py lanes", "batches_in_flight": n_streams, "lane_stagger_ms": round(stagger_ms[0], 1)})},
             "secondary": {"metric": "collision_checks_per_sec", "value": checks_per_s, "unit": "checks/s", "poses": n_chk, "ms": chk_ms,
                           "achieved_GBs": chk_gbs, "hbm_frac": chk_gbs / HBM_PEAK_GBS, "bytes_per_pose_algorithmic": CHECK_BYTES_PER_POSE,
                           "moved_GBs": n_chk * 25.0 / (chk_ms * 1e-3) / 1e9, "moved_frac": n_chk * 25.0 / (chk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -333,9 +433,11 @@ def main():
                             "rs_attempts": sum(r.n_rs_attempts for r in res), "rng_draws": sum(r.n_rng_draws for r in res),
                             "state_checks": state_checks, "path_checks": sum(r.n_path_checks for r in res)},
             "roofline": roof,
+            "roofline_per_kernel": roofs,
+            **({"pipeline_kernel_timings": pipe_kernel, "run_totals": run_sums} if pipeline_mode else {}),
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out, default=lambda o: o.item() if hasattr(o, "item") else str(o)))
     if world > 1:
         dist.destroy_process_group()
 

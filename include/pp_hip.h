@@ -327,7 +327,7 @@ int pp_map_upload_nearest_cells(pp_map* map, const int32_t* nearest_obstacle_hos
 /* ---- streaming form of HybridAStar::SearchPath's search stage (algo/hybrid_a_star.cpp:237-257) ------------------------------
  * One pipeline per GPU: `capacity` queries in flight (a field slot each: the obstacle-heuristic field of its goal, start / goal /
  * seed, path and Reeds-Shepp log), ObstaclesHeuristic::Update by the wavefront kernel, which hands every finished field to ONE
- * persistent search grid of `search_rows` rows (0 = 2048) through a device-side queue; a row takes the next ready query as soon as
+ * persistent search grid of `search_rows` rows (0 = 2304) through a device-side queue; a row takes the next ready query as soon as
  * its own ends, slots are recycled as results are polled.  No batch boundary: a query that exhausts the lattice (~1 s) holds one
  * row, not a batch's 17 GB of fields.  Results per query are exactly those of pp_planner_search_batch (same kernels' device code).
  * log_expansions != 0 keeps the expansion log per slot (parity tests; 4 B x max_nodes_per_query per slot).
@@ -354,6 +354,11 @@ int pp_pipeline_capacity(pp_pipeline* pipeline);
 int pp_pipeline_search_rows(pp_pipeline* pipeline);
 int pp_pipeline_in_flight(pp_pipeline* pipeline);  /* submitted and not yet polled */
 int pp_pipeline_free_slots(pp_pipeline* pipeline);
+/* Kernel launch durations since the last call (HIP events on the launching streams), then reset: total milliseconds / launches / goals of
+ * the wavefront kernel; total milliseconds / launches of the search grid and its longest launch (a launch that tops up a full grid lasts
+ * microseconds, the one that starts it lasts as long as there is work). */
+int pp_pipeline_timings(pp_pipeline* pipeline, double* wavefront_ms_total, int64_t* wavefront_launches, int64_t* wavefront_goals, double* search_ms_total,
+	int64_t* search_launches, double* search_max_ms);
 
 /* last batch: milliseconds spent in the wavefront kernel and in the search kernel (HIP events) */
 int pp_planner_last_timings(pp_planner* planner, float* wavefront_ms, float* search_ms);

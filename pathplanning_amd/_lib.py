@@ -53,6 +53,11 @@ class QueryResult(C.Structure):
                 ("n_lattice_boundary_hits", C.c_int32), ("reserved", C.c_int32)]
 
 
+# the same record as a numpy dtype (arrays of results without a Python loop)
+QUERY_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_expanded", "<i4"), ("n_nodes", "<i4"), ("n_path", "<i4"), ("cost", "<f8"), ("n_rng_draws", "<i4"),
+                               ("n_rs_attempts", "<i4"), ("n_state_checks", "<i8"), ("n_path_checks", "<i8"), ("n_lattice_boundary_hits", "<i4"), ("reserved", "<i4")])
+assert QUERY_RESULT_DTYPE.itemsize == C.sizeof(QueryResult)
+
 # pp_rs_path (include/pp_hip.h): PathReedsShepp as a 128-byte record
 RS_PATH_DTYPE = np.dtype([("start", "<f8", 3), ("final_pose", "<f8", 3), ("motion_length", "<f8", 5), ("steer", "i1", 5), ("direction", "i1", 5),
                           ("reserved", "i1", 6), ("min_turning_radius", "<f8"), ("length", "<f8"), ("cost", "<f4"), ("word", "<i4")])
@@ -166,6 +171,7 @@ def load():
     L.pp_pipeline_poll.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
     L.pp_pipeline_release.argtypes = [vp, C.c_int32, vp]
     L.pp_pipeline_slot_of.argtypes = [vp, C.c_uint64]
+    L.pp_pipeline_timings.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.pp_pipeline_planner.argtypes = [vp]
     L.pp_pipeline_planner.restype = vp
     for f in ("pp_pipeline_capacity", "pp_pipeline_search_rows", "pp_pipeline_in_flight", "pp_pipeline_free_slots"):

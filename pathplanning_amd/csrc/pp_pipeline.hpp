@@ -78,7 +78,17 @@ struct pp_pipeline {
 	std::unordered_map<uint64_t, int32_t> slotOfTicket;
 	unsigned long long nSubmitted = 0, doneHead = 0, nTickets = 0;
 	std::chrono::steady_clock::time_point lastLaunch {};
+	// launch durations (HIP events on the streams the kernels are launched on), harvested by pp_pipeline_poll
+	struct Timed {
+		hipEvent_t a = nullptr, b = nullptr;
+		int kind = 0; // 0 wavefront, 1 search grid
+		long long units = 0; // goals of a wavefront launch
+	};
+	std::vector<Timed> timedFree, timedBusy;
+	double wfMs = 0, searchMs = 0, searchMaxMs = 0;
+	long long wfLaunches = 0, wfGoals = 0, searchLaunches = 0;
 	unsigned long long idleTicks = 12500ull; // idle loop passes of ~4 us: about 50 ms
+	int wfBlocks = 0; // workgroups per wavefront launch (<= the resident number): the wavefront kernel's share of the chip
 };
 
 namespace {
@@ -99,6 +109,13 @@ void free_pipeline(pp_pipeline* P)
 		(void)hipEventDestroy(P->evIngest);
 	if (P->evCtl)
 		(void)hipEventDestroy(P->evCtl);
+	for (auto* v : { &P->timedFree, &P->timedBusy })
+		for (auto& t : *v) {
+			if (t.a)
+				(void)hipEventDestroy(t.a);
+			if (t.b)
+				(void)hipEventDestroy(t.b);
+		}
 	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfCtl[0], P->wfCtl[1] };
 	for (void* q : dev)
 		if (q)
@@ -110,6 +127,55 @@ void free_pipeline(pp_pipeline* P)
 	if (P->pl)
 		free_planner(P->pl);
 	delete P;
+}
+
+/// an event pair around a launch on stream s: take() before the launch, done() after it
+pp_pipeline::Timed timed_take(pp_pipeline* P, hipStream_t s, int kind, long long units)
+{
+	pp_pipeline::Timed t;
+	if (!P->timedFree.empty()) {
+		t = P->timedFree.back();
+		P->timedFree.pop_back();
+	} else if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) {
+		t.a = t.b = nullptr;
+	}
+	t.kind = kind;
+	t.units = units;
+	if (t.a)
+		(void)hipEventRecord(t.a, s);
+	return t;
+}
+void timed_done(pp_pipeline* P, hipStream_t s, const pp_pipeline::Timed& t)
+{
+	if (t.a && t.b) {
+		(void)hipEventRecord(t.b, s);
+		P->timedBusy.push_back(t);
+	}
+}
+void timed_harvest(pp_pipeline* P)
+{
+	for (size_t i = 0; i < P->timedBusy.size();) {
+		pp_pipeline::Timed& t = P->timedBusy[i];
+		if (hipEventQuery(t.b) != hipSuccess) {
+			i++;
+			continue;
+		}
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+			if (t.kind == 0) {
+				P->wfMs += ms;
+				P->wfLaunches++;
+				P->wfGoals += t.units;
+			} else {
+				P->searchMs += ms;
+				P->searchLaunches++;
+				P->searchMaxMs = ms > P->searchMaxMs ? ms : P->searchMaxMs;
+			}
+		}
+		P->timedFree.push_back(t);
+		P->timedBusy[i] = P->timedBusy.back();
+		P->timedBusy.pop_back();
+	}
 }
 
 PipeView pipe_view(const pp_pipeline* P)
@@ -140,10 +206,12 @@ int pipe_launch_search(pp_pipeline* P)
 	constexpr int kWg = PP_ROWS_WAVES_PER_WG;
 	pl->args.rowsWaves = P->waves;
 	pl->args.m = pl->map->view(); // validator tunables may have changed
+	const pp_pipeline::Timed tm = timed_take(P, s, 1, 0);
 	hipLaunchKernelGGL(k_hybrid_search_rows<true>, dim3((P->waves + kWg - 1) / kWg), dim3(64 * kWg), 0, s, pl->args, 0, pl->dStarts, pl->dGoals, pl->dSeeds, pl->costFields, pl->nodes, pl->heaps,
 		pl->keymaps, pl->expanded, pl->rsLogs, pl->paths, pl->mtStates, pl->results, (int*)nullptr, (SuspendRec*)nullptr, (const int32_t*)nullptr, 0, (const SuspendRec*)nullptr,
 		(const int*)nullptr, (int*)nullptr, (int*)nullptr, 0, pl->bands, pl->bandInvW, pl->bandMeta, pipe_view(P));
 	PP_HIP_TRY(hipGetLastError());
+	timed_done(P, s, tm);
 	P->lastLaunch = std::chrono::steady_clock::now();
 	return PP_OK;
 }
@@ -162,7 +230,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	auto* P = new pp_pipeline();
 	P->capacity = capacity;
 	if (search_rows == 0)
-		search_rows = 2048; // a quarter of the chip's resident rows: the wavefront kernel needs the other CUs
+		search_rows = 2304; // measured optimum on MI355X (profiles/r03_pipeline_sweep.txt): beyond it the wavefront kernel, which needs the other CUs' registers, becomes the bottleneck
 	if (int rc = create_planner(map, params, capacity, max_nodes_per_query, search_rows, log_expansions ? PlannerUse::PipelineLogged : PlannerUse::Pipeline, &P->pl)) {
 		delete P;
 		return rc;
@@ -228,6 +296,12 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	pl->hostResults.resize((size_t)capacity);
 	pl->lastBatch = capacity;
 	{
+		P->wfBlocks = pl->wfSlots;
+		if (const char* b = getenv("PP_PIPE_WF_BLOCKS")) { // tuning: fewer resident wavefront workgroups leave more of the chip to the search grid
+			const long x = strtol(b, nullptr, 10);
+			if (x >= 1 && x < P->wfBlocks)
+				P->wfBlocks = (int)x;
+		}
 		const char* v = getenv("PP_PIPE_IDLE_MS"); // how long a wave waits for work that does not come before it leaves on its own
 		if (v && *v) {
 			const long ms = strtol(v, nullptr, 10);
@@ -314,8 +388,10 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	pub.readyTail = &P->ctl->readyTail;
 	pub.ready = P->ready;
 	pub.readyMask = P->readyMask;
-	PP_HIP_TRY(pph::launch_wavefront(w, pl->args.m, k, nullptr, pl->costFields, wws, pl->wfBytesPerSlot, pl->wfSlots, wctl, nullptr, /*tiledOut=*/true, /*goalPoses=*/pl->dGoals,
+	const pp_pipeline::Timed tm = timed_take(P, w, 0, k);
+	PP_HIP_TRY(pph::launch_wavefront(w, pl->args.m, k, nullptr, pl->costFields, wws, pl->wfBytesPerSlot, P->wfBlocks, wctl, nullptr, /*tiledOut=*/true, /*goalPoses=*/pl->dGoals,
 		/*countersZeroed=*/true, nullptr, nullptr, nullptr, nullptr, pub));
+	timed_done(P, w, tm);
 	P->nSubmitted += (unsigned long long)k;
 	*n_accepted = k;
 	return pipe_launch_search(P);
@@ -385,6 +461,7 @@ int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out,
 		n++;
 	}
 	*n_out = n;
+	timed_harvest(P);
 	// the wavefront kernels' error flags come over asynchronously; what an earlier poll asked for is looked at now
 	if (P->errStage[0] || P->errStage[1]) {
 		set_error("obstacle-heuristic open list exceeded its workspace");
@@ -418,6 +495,34 @@ int pp_pipeline_release(pp_pipeline* P, int32_t n, const uint64_t* tickets)
 		P->freeSlots.push_back(it->second);
 		P->slotOfTicket.erase(it);
 	}
+	return PP_OK;
+}
+
+/// Launch durations seen so far (HIP events on the launching streams; harvested by pp_pipeline_poll) and reset.  Wavefront: one launch per
+/// submission.  Search grid: every submission launches the grid, but only waves whose index is free stay -- a launch that tops up
+/// a full grid lasts microseconds, the launch that (re)starts it lasts until the work runs out; search_max_ms is the longest.
+int pp_pipeline_timings(pp_pipeline* P, double* wavefront_ms_total, int64_t* wavefront_launches, int64_t* wavefront_goals, double* search_ms_total, int64_t* search_launches,
+	double* search_max_ms)
+{
+	if (!P) {
+		set_error("null pipeline");
+		return PP_ERR_INVALID;
+	}
+	timed_harvest(P);
+	if (wavefront_ms_total)
+		*wavefront_ms_total = P->wfMs;
+	if (wavefront_launches)
+		*wavefront_launches = P->wfLaunches;
+	if (wavefront_goals)
+		*wavefront_goals = P->wfGoals;
+	if (search_ms_total)
+		*search_ms_total = P->searchMs;
+	if (search_launches)
+		*search_launches = P->searchLaunches;
+	if (search_max_ms)
+		*search_max_ms = P->searchMaxMs;
+	P->wfMs = P->searchMs = P->searchMaxMs = 0;
+	P->wfLaunches = P->wfGoals = P->searchLaunches = 0;
 	return PP_OK;
 }
 

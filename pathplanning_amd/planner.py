@@ -680,6 +680,22 @@ class HybridAStarPipeline:
                 self._held[int(tickets[i])] = res[i]
         return tickets[:k.value], res
 
+    def poll_array(self, max_results=4096):
+        """poll(release=True) as numpy arrays: (tickets [k] uint64, results [k] of _lib.QUERY_RESULT_DTYPE)"""
+        from ._lib import QUERY_RESULT_DTYPE
+        tickets = np.empty(max_results, dtype=np.uint64)
+        res = np.empty(max_results, dtype=QUERY_RESULT_DTYPE)
+        k = C.c_int32(0)
+        check(self.lib.pp_pipeline_poll(self.h, int(max_results), ptr(tickets), ptr(res), 1, C.byref(k)))
+        return tickets[:k.value], res[:k.value]
+
+    def timings(self):
+        """kernel launch durations since the last call (pp_pipeline_timings), as a dict"""
+        a, d, f = C.c_double(), C.c_double(), C.c_double()
+        b, c, e = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self.lib.pp_pipeline_timings(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e), C.byref(f)))
+        return dict(wavefront_ms_total=a.value, wavefront_launches=b.value, wavefront_goals=c.value, search_ms_total=d.value, search_launches=e.value, search_max_ms=f.value)
+
     def in_flight(self):
         return self.lib.pp_pipeline_in_flight(self.h)
 
