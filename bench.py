@@ -61,6 +61,8 @@ def main():
                          "device-side queue, field slots recycled; lanes: round 2's scheduling, --streams batch planners refilled by this script")
     ap.add_argument("--capacity", type=int, default=0, help="--mode pipeline: queries in flight (field slots); 0 = 6 steps' worth")
     ap.add_argument("--pipe-rows", type=int, default=2304, help="--mode pipeline: rows of the persistent search grid")
+    ap.add_argument("--map-source", choices=("product", "synthetic"), default="product",
+                    help="product: outlines -> pp_map_set_cells -> pp_map_update_gvd_ex(REFERENCE_ORDER) (the library's own map pipeline); synthetic: numpy / scipy generator of rounds 1-2")
     ap.add_argument("--submit-chunk", type=int, default=2048, help="--mode pipeline: queries per submission (= per wavefront launch)")
     args = ap.parse_args()
 
@@ -90,7 +92,16 @@ def main():
     # the map set is made on rank 0 and broadcast (RCCL; 13 MB at 1024^2) -- what a deployment does with a map that exists on one
     # rank only; the broadcast is outside the timed region, like the upload that follows it
     from pathplanning_amd import sharding as _sh
-    m = synthetic.make_map(args.cells, args.obstacles, seed=1) if rank == 0 or world == 1 else None
+    # the map is built THROUGH THE PRODUCT (outlines rasterised on the device, GVD::Update in reference order), outside the timed region;
+    # --map-source synthetic: round 1-2's numpy / scipy generator (dense-sampled outlines, scipy's EDT)
+    map_info = None
+    if rank == 0 or world == 1:
+        if args.map_source == "product":
+            m, map_info = synthetic.make_map_product(pa.Context(local_rank), args.cells, args.obstacles, seed=1)
+        else:
+            m = synthetic.make_map(args.cells, args.obstacles, seed=1)
+    else:
+        m = None
     if world > 1:
         m = _sh.broadcast_map_set(m, 0, rank, world, device=dev)
     params = pa.HybridAStarSearchParameters()
@@ -434,6 +445,7 @@ def main():
                             "state_checks": state_checks, "path_checks": sum(r.n_path_checks for r in res)},
             "roofline": roof,
             "roofline_per_kernel": roofs,
+            "map_build": map_info,
             **({"pipeline_kernel_timings": pipe_kernel, "run_totals": run_sums} if pipeline_mode else {}),
             "cpu_baseline": cpu,
         }

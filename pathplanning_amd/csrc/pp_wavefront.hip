@@ -272,6 +272,26 @@ __device__ __forceinline__ uint32_t candidate_mask(const Row3& up, const Row3& m
 	return mk;
 }
 
+/// +inf into the output field for every map cell whose state byte is not "discovered" (one pass over the tiled state grid when a goal
+/// is done; see k_wavefront).  NOT inlined on purpose: inlined, its registers cost the round loop eight scratch stores per round.
+__device__ __attribute__((noinline)) void fill_unreached(const uint8_t* __restrict__ state, int64_t stWords, int tpr, int rows, int cols, int tiledOut, float* __restrict__ cost, int tid)
+{
+	for (int64_t t = tid; t < stWords; t += WF_T) {
+		const unsigned long long v = reinterpret_cast<const unsigned long long*>(state)[t];
+		const int tile = (int)(t >> 3), trow = (int)(t & 7);
+		const int tr = tile / tpr, tc = tile - tr * tpr;
+		const int r = (tr << 3) + trow - 1;
+		if (r < 0 || r >= rows)
+			continue;
+#pragma unroll
+		for (int x = 0; x < 8; x++) {
+			const int c = (tc << 3) + x - 1;
+			if (c >= 0 && c < cols && (uint32_t)((v >> (8 * x)) & 0xFFull) != ST_SEEN)
+				reinterpret_cast<uint32_t*>(cost)[tiledOut ? field_tiled_index(cols, r, c) : (size_t)r * cols + c] = kInfBits;
+		}
+	}
+}
+
 // kProfile: diagnostic build -- per goal {init, min, partition, sort, offer, push, tail} shader-clock sums + rounds, sum(w), sum(P)
 enum { WP_INIT = 0, WP_MIN, WP_PART, WP_SORT, WP_OFFER, WP_PUSH, WP_TAIL, WP_ROUNDS, WP_SUMW, WP_SUMP, WP_FBROUNDS, WP_FBCYC, WP_O_WAIT, WP_O_LOAD, WP_O_COUNT, WP_O_INSERT, WP_P_LOOKUP, WP_P_SCAN, WP_P_STORE, WP_P_PAD, WP_COUNT };
 
@@ -592,8 +612,19 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			tl = clock64();
 		}
 		float* cost = costOut + (int64_t)g * fieldElems;
-		// ---- every cell starts at +inf / unexplored (heuristics.cpp:108-113); state: occupied cells and the border
-		{
+		int32_t start;
+		if (goalPoses) { // (x, y, theta) triples: WorldPositionToGridCell(bounded), heuristics.cpp:115
+			int row, col;
+			world_to_cell(m, goalPoses[3 * g], goalPoses[3 * g + 1], row, col);
+			start = inside_map(m, row, col) ? row * m.cols + col : -1;
+		} else {
+			start = goalCells[g];
+		}
+		// ---- every cell starts at +inf / unexplored (heuristics.cpp:108-113).  The field is NOT filled up front: every cell the wavefront
+		// discovers is written exactly once, with its cost, and the cells it never reaches (occupied ones, enclosed pockets) get their +inf
+		// in one pass over the state bytes when the goal is done -- 4 MB of stores per goal less at 1024^2, and the lines of the field
+		// are dirtied once instead of twice.  Only a goal outside the map (nothing is discovered) fills the whole field.
+		if (start < 0) {
 			uint4* c4 = reinterpret_cast<uint4*>(cost); // fieldElems * 4 bytes is a multiple of 16 when tiled; row-major: tail below
 			const int64_t n4 = fieldElems >> 2;
 #if PP_WF_NT_FILL
@@ -607,6 +638,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 #endif
 			for (int64_t i = (n4 << 2) + tid; i < fieldElems; i += WF_T)
 				reinterpret_cast<uint32_t*>(cost)[i] = kInfBits;
+			continue; // goal outside the map (heuristics.cpp:115-117): the field stays +inf
 		}
 		// one tile row (8 bytes) per thread and step; everything outside the map is "occupied"
 		for (int64_t t = tid; t < (stBytes >> 3); t += WF_T) {
@@ -624,14 +656,6 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			}
 			reinterpret_cast<unsigned long long*>(state)[t] = v;
 		}
-		int32_t start;
-		if (goalPoses) { // (x, y, theta) triples: WorldPositionToGridCell(bounded), heuristics.cpp:115
-			int row, col;
-			world_to_cell(m, goalPoses[3 * g], goalPoses[3 * g + 1], row, col);
-			start = inside_map(m, row, col) ? row * m.cols + col : -1;
-		} else {
-			start = goalCells[g];
-		}
 		if (tid == 0) {
 			s_minNext[0] = 0xFFFFFFFFu;
 			s_minNext[1] = 0xFFFFFFFFu;
@@ -639,8 +663,6 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			s_cand = 0;
 		}
 		__syncthreads();
-		if (start < 0)
-			continue; // goal outside the map (heuristics.cpp:115-117): the field stays +inf
 		bool inLds = packable; // where the open list lives
 		int cur = 0;           // ping-pong index of the HBM list
 		if (tid == 0) {
@@ -1138,6 +1160,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		}
 		if (overflow && tid == 0)
 			*errorFlag = 1; // open list / round count beyond the workspace encoding
+		__syncthreads(); // (the last round's state stores are visible)
+		// ---- +inf for every map cell the wavefront never discovered (see the note at the top of the goal)
+		// (arguments recomputed from the kernel arguments: nothing extra stays live across the round loop for this call)
+		fill_unreached(S.state, state_bytes(m.rows, m.cols) >> 3, state_tiles_per_row(m.cols), m.rows, m.cols, tiledOut, costOut + (int64_t)g * fieldElems, (int)threadIdx.x);
 		__syncthreads();
 		if (orderOut && tid == 0) {
 			// hand-out key of this query: the field value at its start pose, published with a device-scope store (the

@@ -45,11 +45,12 @@ def poses_of_record(row):
     return int(row[0]), float(row[1]), int(row[2]), row[4:4 + 3 * k].reshape(k, 3)
 
 
-def gather_records(local_records, n_queries, rank, world, device=None):
-    """all_gather of the per-rank record blocks (padded to equal length) -> [n_queries, fields] in query order."""
+def gather_records(local_records, n_queries, rank, world, device=None, force_collective=False):
+    """all_gather of the per-rank record blocks (padded to equal length) -> [n_queries, fields] in query order.
+    force_collective: run the collective even with one rank (exercises the backend's device-tensor path on a one-GPU box)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force_collective:
         return local_records
     per = (n_queries + world - 1) // world
     buf = torch.zeros(per, local_records.shape[1], dtype=torch.float64)
@@ -65,13 +66,13 @@ def gather_records(local_records, n_queries, rank, world, device=None):
     return out
 
 
-def broadcast_map_set(m, src, rank, world, device=None):
+def broadcast_map_set(m, src, rank, world, device=None, force_collective=False):
     """The map set of rank `src` on every rank: {lower, upper, resolution, occ, d2, path_cost} (the dict of synthetic.make_map, or
     grids loaded from elsewhere on one rank only).  A 16-double header carries the sizes, then one broadcast per grid
     (13 MB at 1024^2, 200 MB at 4096^2: xGMI-trivial, done once per map).  Ranks other than `src` pass m=None."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force_collective:
         return m
     head = torch.zeros(16, dtype=torch.float64)
     if rank == src:

@@ -68,6 +68,41 @@ def make_map(n_cells, n_obstacles, seed, resolution=0.1):
     return dict(lower=lower, upper=upper, resolution=resolution, occ=occ, d2=d2, path_cost=path_cost)
 
 
+def make_map_product(ctx, n_cells, n_obstacles, seed, resolution=0.1, reference_order=True):
+    """The same K rectangle outlines as make_map, but built THROUGH THE PRODUCT: vertices rotated / translated on the host
+    (PolygonShape::GetVerticesPosition), outlines rasterised by the device's Bresenham in AddObstacle order (pp_rasterize_cells +
+    pp_map_set_cells), GVD::Update by pp_map_update_gvd_ex -- reference_order=True: the reference's own brushfire, its grids bit for
+    bit (host replay, seconds); False: the exact Euclidean transform on the device (milliseconds).  Returns (m, info): m = the dict
+    make_map returns (grids downloaded from the device), info = build times in ms."""
+    import time
+    from .planner import OccupancyMapSet
+    half = n_cells * resolution / 2.0
+    lower = np.array([-half, -half, -math.pi])
+    upper = np.array([half, half, math.pi])
+    ms = OccupancyMapSet.from_bounds(ctx, lower, upper, resolution)
+    assert (ms.rows, ms.cols) == (n_cells, n_cells)
+    rng = np.random.RandomState(seed)
+    dx, dy = 0.3 * half / 2.0, 0.04 * half / 2.0
+    corners = [(dx, dy), (-dx, dy), (-dx, -dy), (dx, -dy)]  # RectangleShape, obstacle.cpp:105-110
+    t0 = time.perf_counter()
+    for k in range(n_obstacles):
+        cx, cy = rng.uniform(-0.7 * half, 0.7 * half, 2)
+        th = rng.uniform(-math.pi, math.pi)
+        ms.add_polygon(corners, [cx, cy, th], k)
+    t1 = time.perf_counter()
+    ms.update_gvd(mode=ms.GVD_EXACT_EDT)  # timed for the line; its grids are replaced below when reference_order
+    t2 = time.perf_counter()
+    if reference_order:
+        ms.update_gvd(mode=ms.GVD_REFERENCE_ORDER)
+    t3 = time.perf_counter()
+    g = ms.download_gvd()
+    m = dict(lower=lower, upper=upper, resolution=resolution, occ=ms.download_occupancy(), d2=g["d2"], path_cost=g["path_cost"])
+    ms.close()
+    info = dict(outlines_ms=(t1 - t0) * 1e3, gvd_exact_transform_ms=(t2 - t1) * 1e3, gvd_reference_order_ms=(t3 - t2) * 1e3 if reference_order else None,
+                fields="reference order (host brushfire replay)" if reference_order else "exact transform (device)")
+    return m, info
+
+
 def upload(ctx, m):
     """Creates the device map set + validator from make_map()'s dict."""
     from .planner import OccupancyMapSet, StateValidatorOccupancyMap

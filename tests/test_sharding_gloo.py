@@ -139,3 +139,45 @@ def test_two_rank_gloo_sharding_matches_single_process():
 @pytest.mark.gpu
 def test_two_ranks_plan_on_the_gpu_and_match_the_oracle():
     _run_two_ranks("gpu")
+
+
+def _rccl_one_rank(port, ret):
+    """child process: RCCL (backend "nccl") with world_size 1 on cuda:0, device tensors through both collectives of the sharding path"""
+    try:
+        import torch
+        import torch.distributed as dist
+        from pathplanning_amd import sharding, synthetic
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        dev = torch.device("cuda", 0)
+        m = synthetic.make_map(256, 6, seed=3)
+        got = sharding.broadcast_map_set(m, 0, 0, 1, device=dev, force_collective=True)  # header + three grids (int32, int32, float32) as device tensors
+        ok_map = all(np.array_equal(got[k], np.asarray(m[k])) for k in ("occ", "d2", "path_cost", "lower", "upper")) and got["resolution"] == float(m["resolution"])
+        rec = np.random.RandomState(1).uniform(-5, 5, (37, sharding.record_width(8)))
+        out = sharding.gather_records(rec, 37, 0, 1, device=dev, force_collective=True)  # all_gather of float64 device tensors
+        t = torch.ones(4, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's elapsed-time reduction
+        dist.barrier()
+        dist.destroy_process_group()
+        ret.put((ok_map, bool(np.array_equal(out, rec)), float(t.sum().item())))
+    except Exception as e:  # the parent reports it
+        ret.put(("error", repr(e), 0.0))
+
+
+@pytest.mark.gpu
+def test_rccl_backend_carries_the_sharding_collectives_on_device_tensors():
+    """Every multi-rank run so far used gloo.  RCCL refuses two ranks on one device, so on a one-GPU box it is exercised with
+    world_size 1: the `nccl` process group is initialised and the map-set broadcast (header + int32 / float32 grids), the record
+    all_gather (float64) and bench.py's all_reduce run as real collectives on device tensors (force_collective skips the
+    single-rank short cuts)."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank, args=(29500 + (os.getpid() % 2000) + 3, ret))
+    p.start()
+    got = ret.get(timeout=600)
+    p.join(timeout=120)
+    assert got[0] is True and got[1] is True and got[2] == 4.0, got
+    assert p.exitcode == 0
