@@ -1822,6 +1822,88 @@ int pp_planner_debug_node_actions(pp_planner* planner, int32_t q, int32_t max_no
 	return PP_OK;
 }
 
+/// SURVEY 7.3 H2 as a contract.  Every constant-steer child's pose is recomputed on the HOST with the C library the reference links
+/// (glibc sin / cos), along its own chain of ancestors from the start pose -- the arithmetic the reference performs for that node
+/// (KinematicBicycleModel::ConstantSteer, models/kinematic_bicycle_model.cpp:5-32, through PathConstantSteer::Interpolate with the
+/// stored, possibly truncated, length) -- and discretised (HybridAStar::DiscretizePose, algo/hybrid_a_star.h:104-111).  A node whose
+/// cell differs from the cell of the device's pose is a place where this libm and glibc disagree about a lattice boundary:
+/// n_cell_mismatches == 0 certifies every discrete pose of the query's search tree.  Needs the tree, i.e. a planner of the
+/// one-query-per-wave kind (max_batch <= 64 or PP_SEARCH_ROWS=0); queries of a throughput planner or pipeline that report
+/// n_lattice_boundary_hits > 0 are re-planned on such a planner (same kernels' device code, same results) and certified there.
+int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_nodes_checked, int32_t* n_cell_mismatches, double* max_pose_difference)
+{
+	if (!planner || q < 0 || q >= planner->lastBatch || (int)planner->hostResults.size() <= q) {
+		set_error("no fetched result for this query (call pp_planner_fetch_results first)");
+		return PP_ERR_INVALID;
+	}
+	if (planner->rowsKernel) {
+		set_error("the search tree is kept per query by the one-query-per-wave kernel only (PP_SEARCH_ROWS=0 or max_batch <= 64)");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
+	const int n = planner->hostResults[q].r.n_nodes;
+	std::vector<Node> nodes((size_t)(n > 0 ? n : 0));
+	if (n > 0)
+		PP_HIP_TRY(hipMemcpy(nodes.data(), planner->nodes + (size_t)q * planner->maxNodes, (size_t)n * sizeof(Node), hipMemcpyDeviceToHost));
+	const SearchArgs& A = planner->args;
+	auto wrap = [](double t) { // geometry/2dplane.h:36-45
+		while (t > M_PI)
+			t -= 2 * M_PI;
+		while (t < -M_PI)
+			t += 2 * M_PI;
+		return t;
+	};
+	auto cell = [&](double x, double y, double t, int c[3]) { // hybrid_a_star.h:104-111 (x86 conversions; the bins before WrapTheta's aliasing)
+		c[0] = (int)(x / A.rp.spatialRes);
+		c[1] = (int)(y / A.rp.spatialRes);
+		c[2] = (int)(wrap(t) / A.rp.angularRes);
+	};
+	std::vector<double> hx((size_t)n), hy((size_t)n), ht((size_t)n);
+	int checked = 0, bad = 0;
+	double worst = 0.0;
+	for (int i = 0; i < n; i++) {
+		const Node& nd = nodes[(size_t)i];
+		const int a = nd.action;
+		if (nd.parent < 0 || nd.parent >= i || a < 0 || a >= A.prims.n) { // root; Reeds-Shepp child (its pose is the path's end, not an arc's)
+			hx[(size_t)i] = nd.x;
+			hy[(size_t)i] = nd.y;
+			ht[(size_t)i] = nd.t;
+			continue;
+		}
+		const size_t p = (size_t)nd.parent;
+		const double kappa = A.prims.kappa[a];
+		const double dist = A.prims.backward[a] ? -nd.length : nd.length;
+		double x = hx[p], y = hy[p], t = ht[p];
+		if (std::fabs(kappa) > 1e-9) { // kinematic_bicycle_model.cpp:22-26 with beta = 0
+			const double t0 = t;
+			t += dist * kappa;
+			x += 1 / kappa * (std::sin(t) - std::sin(t0));
+			y += 1 / kappa * (-std::cos(t) + std::cos(t0));
+		} else {
+			x += dist * std::cos(t);
+			y += dist * std::sin(t);
+		}
+		hx[(size_t)i] = x;
+		hy[(size_t)i] = y;
+		ht[(size_t)i] = t;
+		int ch[3], cd[3];
+		cell(x, y, t, ch);
+		cell(nd.x, nd.y, nd.t, cd);
+		checked++;
+		if (ch[0] != cd[0] || ch[1] != cd[1] || ch[2] != cd[2])
+			bad++;
+		const double d = std::fmax(std::fmax(std::fabs(x - nd.x), std::fabs(y - nd.y)), std::fabs(t - nd.t));
+		worst = d > worst ? d : worst;
+	}
+	if (n_nodes_checked)
+		*n_nodes_checked = checked;
+	if (n_cell_mismatches)
+		*n_cell_mismatches = bad;
+	if (max_pose_difference)
+		*max_pose_difference = worst;
+	return PP_OK;
+}
+
 int pp_planner_search_rows(pp_planner* planner) { return planner && planner->rowsKernel ? planner->searchRows : 0; }
 
 int pp_planner_set_profiling(pp_planner* planner, int32_t enable)

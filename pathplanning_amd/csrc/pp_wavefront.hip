@@ -245,6 +245,9 @@ constexpr uint32_t ST_FREE = 0u, ST_OCC = 1u, ST_SEEN = 2u; // state grid values
 #ifndef PP_WF_NT_COST
 #define PP_WF_NT_COST 0
 #endif
+#ifndef PP_WF_DEFER_STORES
+#define PP_WF_DEFER_STORES 1 // v11: the state / cost stores of a round's discoveries are issued densely at the start of the next round
+#endif
 #ifndef PP_WF_NT_FILL
 #define PP_WF_NT_FILL 0
 #endif
@@ -680,10 +683,28 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		WF_STAMP(WP_INIT);
 		uint32_t n = 1; // open-list size
 		uint32_t round = 0;
+		uint32_t deferFrom = 0xFFFFFFFFu; // first open-list entry whose state / cost stores are still owed (see the top of the round loop)
 		uint32_t lBits = 0u; // smallest cost in the open list
 		bool overflow = false;
 
 		while (n > 0) {
+#if PP_WF_DEFER_STORES
+			// The cells the previous round discovered sit at the end of the (LDS) list, cost and cell in every entry; their "discovered"
+			// byte and their cost are stored HERE, one entry per lane, instead of inside that round's push loop, where every lane walked
+			// its own wins (a wave iterated as often as its busiest lane had wins, two scattered stores per pass).  Same bytes to the same
+			// addresses, before anything reads them: the next reader of the state grid is this round's neighbourhood pass, behind a full
+			// barrier; the field is not read by this kernel at all.
+			if (deferFrom != 0xFFFFFFFFu) {
+				for (uint32_t i = deferFrom + (uint32_t)tid; i < n; i += WF_T) {
+					const uint64_t e = lent[i];
+					const uint32_t ncell = (uint32_t)e;
+					const int nr = (int)(ncell >> 16), nc = (int)(ncell & 0xFFFFu);
+					state[st_addr(tpr, nr, nc)] = (uint8_t)ST_SEEN;
+					store_cost(&cost[out_index(nr - 1, nc - 1)], __uint_as_float((uint32_t)(e >> 32)));
+				}
+				deferFrom = 0xFFFFFFFFu;
+			}
+#endif
 			uint64_t* const fentCur = cur ? fent1 : fent0;
 			uint64_t* const fentNxt = cur ? fent0 : fent1;
 			const int par = (int)(round & 1u);
@@ -1005,9 +1026,14 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						const float transitionCost = (dr == 0 || dc == 0) ? 1.0f : kDiag;
 						const float pathCost = transitionCost + __uint_as_float(myCost[q]); // heuristics.cpp:135
 						const uint32_t pb = __float_as_uint(pathCost);
-						const int nr = (int)(ncell >> 16), nc = (int)(ncell & 0xFFFFu);
-						state[st_addr(tpr, nr, nc)] = (uint8_t)ST_SEEN;
-						store_cost(&cost[out_index(nr - 1, nc - 1)], pathCost);
+#if PP_WF_DEFER_STORES
+						if (!pushLds) // (entries that stay in LDS are stored from there at the start of the next round)
+#endif
+						{
+							const int nr = (int)(ncell >> 16), nc = (int)(ncell & 0xFFFFu);
+							state[st_addr(tpr, nr, nc)] = (uint8_t)ST_SEEN;
+							store_cost(&cost[out_index(nr - 1, nc - 1)], pathCost);
+						}
 						newMin = min(newMin, pb);
 						push_entry(slot++, ncell, pb);
 					}
@@ -1118,6 +1144,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				}
 				newCount = runBase - b;
 			}
+#if PP_WF_DEFER_STORES
+			if (hashed && pushLds && newCount > 0)
+				deferFrom = b;
+#endif
 			if (kProfile && hashed)
 				ph[WP_P_STORE] += clock64() - tl;
 			newMin = wave_min(newMin);

@@ -571,6 +571,13 @@ class HybridAStarBatch:
         return dict(sampled=sampled, cusp=cusp.astype(bool), smoothed=smoothed, status=r.smoothing_status, iterations=r.iterations, length=r.length,
                     path=smoothed if r.smoothing_status >= 0 else sampled)
 
+    def certify_lattice(self, q):
+        """SURVEY 7.3 H2 as a contract (pp_planner_certify_lattice): every constant-steer node of query q's tree recomputed on the host with
+        glibc and discretised; returns (nodes checked, cell mismatches, largest pose difference).  One-query-per-wave planners only."""
+        a, b, d = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        check(self.lib.pp_planner_certify_lattice(self.h, int(q), C.byref(a), C.byref(b), C.byref(d)))
+        return a.value, b.value, d.value
+
     def get_expanded_of(self, q):
         r = self._results[q]
         cells = np.empty((r.n_expanded, 3), dtype=np.int32)

@@ -407,6 +407,54 @@ def test_lattice_guard_band_counter():
         assert (hits[0::2] > 0).sum() >= on_lattice, hits
 
 
+def test_lattice_certification_on_boundary_poses(monkeypatch):
+    """SURVEY 7.3 H2 as a contract: starts AND goals on exact multiples of the spatial resolution (x or y an integer number of metres,
+    heading a multiple of the angular resolution) -- the case where a last-bit difference between this libm and glibc can put a child on
+    the other side of a lattice line (y + (cos t - cos t') / kappa lands on an integer +- 1e-16).  Every such query reports
+    n_lattice_boundary_hits > 0; pp_planner_certify_lattice recomputes every constant-steer node of its tree on the host with glibc.
+    The contract: a query with 0 mismatching cells equals the oracle in every discrete output, and EVERY query that deviates from the
+    oracle is caught (mismatches > 0: hand it to the CPU reference)."""
+    w, ms, val, ctx = make_pair(192, 4, 31)
+    rng = np.random.RandomState(21)
+    cand_s, cand_g = valid_random_poses(rng, w, 400), valid_random_poses(rng, w, 400)
+    ares = 0.0872
+    starts, goals = [], []
+    for s_, g_ in zip(cand_s, cand_g):
+        s2 = np.array([np.round(s_[0]), np.round(s_[1]), np.round(s_[2] / ares) * ares])
+        g2 = np.array([np.round(g_[0]), g_[1], np.round(g_[2] / ares) * ares])
+        if w.is_state_valid(np.array([s2, g2])).all():
+            starts.append(s2)
+            goals.append(g2)
+        if len(starts) == 24:
+            break
+    assert len(starts) >= 12
+    starts, goals = np.array(starts), np.array(goals)
+    seeds = np.arange(len(starts), dtype=np.uint64) + 400
+    planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=0)  # one query per wave: the tree is kept
+    clean, caught, total_checked = 0, 0, 0
+    for q in range(len(starts)):
+        assert res[q].n_lattice_boundary_hits > 0
+        r = h.search(starts[q], goals[q], int(seeds[q]))
+        g = res[q]
+        same = (g.status == r["status"] and g.n_expanded == len(r["expanded"]) and np.array_equal(planner.get_expanded_of(q), r["expanded"]) and g.n_nodes == r["n_nodes"]
+                and g.n_rng_draws == r["n_rng_draws"] and g.n_rs_attempts == r["n_rs_attempts"] and g.n_state_checks == r["n_state_checks"] and g.n_path_checks == r["n_path_checks"]
+                and (r["status"] != 0 or abs(g.cost - r["cost"]) < 1e-5))
+        checked, mismatches, worst = planner.certify_lattice(q)
+        assert worst < 1e-9, (q, worst)  # the poses themselves agree far below the parity tolerance either way
+        assert same or mismatches > 0, (q, "deviates from the oracle, not caught", checked, mismatches)
+        clean += mismatches == 0
+        caught += mismatches > 0
+        total_checked += checked
+    print("lattice certification: %d queries on lattice lines, %d certified, %d flagged for the CPU reference, %d nodes recomputed" % (len(starts), clean, caught, total_checked))
+    assert total_checked > 1000 and clean >= 1
+    # a throughput planner keeps no tree: the call says so instead of certifying nothing
+    monkeypatch.setenv("PP_SEARCH_ROWS", "1")
+    rows, res_rows, _ = run_pair(w, ms, val, {}, starts, goals, seeds, search_rows=8)
+    assert rows.search_rows == 8
+    with pytest.raises(Exception):
+        rows.certify_lattice(0)
+
+
 def test_chained_planners_give_the_same_results():
     """pp_planner_start_after_fields_of is scheduling only: two planners on their own streams, the second one's batch held back until
     the first one's heuristic fields are built, return what they return unchained; chaining a planner to itself is refused."""
