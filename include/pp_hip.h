@@ -324,13 +324,15 @@ int pp_planner_get_processed_path(pp_planner* planner, int32_t q, double* sample
 /* (row, col) per cell, row-major, (-1, -1) = none: the two label grids of the reference's GVD for maps whose fields were built elsewhere */
 int pp_map_upload_nearest_cells(pp_map* map, const int32_t* nearest_obstacle_host, const int32_t* nearest_edge_host);
 
-/* The guard band of the lattice as a contract (pp_query_result::n_lattice_boundary_hits > 0 marks the queries it concerns): every
- * constant-steer child of query q's search tree recomputed on the host with glibc along its ancestors (ConstantSteer,
- * models/kinematic_bicycle_model.cpp:5-32) and discretised (DiscretizePose, algo/hybrid_a_star.h:104-111); n_cell_mismatches = nodes
- * whose cell differs from the device's.  0 certifies the query's discrete poses against the reference's arithmetic; > 0: hand the
- * query to the CPU reference.  One-query-per-wave planners only (max_batch <= 64): they keep the tree; flagged queries of a
- * throughput planner / pipeline are re-planned there first (identical results). */
-int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_nodes_checked, int32_t* n_cell_mismatches, double* max_pose_difference);
+/* The guard band of the lattice as a contract (pp_query_result::n_lattice_boundary_hits > 0 marks the queries it concerns: some child's
+ * DiscretizePose quotient lay within 1e-9 cells of a lattice line, where a last-bit difference between this libm and glibc could
+ * choose the other cell).  The host recomputes every created constant-steer node and every LOGGED lattice-line child of query q with
+ * glibc along its ancestors (ConstantSteer, models/kinematic_bicycle_model.cpp:5-32) and discretises it (DiscretizePose,
+ * algo/hybrid_a_star.h:104-111).  n_cell_mismatches: cells that differ from the device's; n_unverified: flagged events that cannot
+ * be recomputed (a Reeds-Shepp child on a lattice line, log entries beyond 64).  Both 0: the query's discrete outputs are certified
+ * against the reference's arithmetic; else hand it to the CPU reference.  One-query-per-wave planners only (max_batch <= 64): they
+ * keep the tree and the log; flagged queries of a throughput planner / pipeline are re-planned there first (identical results). */
+int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_checked, int32_t* n_cell_mismatches, int32_t* n_unverified, double* max_pose_difference);
 
 /* ---- streaming form of HybridAStar::SearchPath's search stage (algo/hybrid_a_star.cpp:237-257) ------------------------------
  * One pipeline per GPU: `capacity` queries in flight (a field slot each: the obstacle-heuristic field of its goal, start / goal /

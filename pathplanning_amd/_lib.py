@@ -153,7 +153,7 @@ def load():
     L.pp_planner_search_rows.argtypes = [vp]
     L.pp_planner_debug_nodes.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
     L.pp_planner_debug_node_actions.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
-    L.pp_planner_certify_lattice.argtypes = [vp, C.c_int32, vp, vp, vp]
+    L.pp_planner_certify_lattice.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
     L.pp_planner_create_ex.argtypes = [vp, C.POINTER(HybridParams), C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.pp_planner_destroy.argtypes = [vp]
     L.pp_planner_set_nonholo_table.argtypes = [vp, vp]

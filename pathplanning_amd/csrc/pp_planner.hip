@@ -93,6 +93,18 @@ struct KeySpace {
 	__host__ __device__ size_t size() const { return (size_t)nx * ny * nt; }
 };
 
+/// A child whose DiscretizePose quotient lay within 1e-9 cells of a lattice line (pp_device.hpp: near_integer), logged by the
+/// one-query-per-wave kernel for pp_planner_certify_lattice: the node it was generated from, the primitive, the (possibly truncated)
+/// arc length and the cell the DEVICE put it in.  kind 1: constant-steer child; 2: Reeds-Shepp child (not recomputable on the host)
+struct GuardRec {
+	int32_t parent;
+	int16_t prim, kind;
+	double length;
+	int32_t ix, iy, it, pad;
+};
+static_assert(sizeof(GuardRec) == 32, "GuardRec layout");
+constexpr int kGuardLogCap = 64; // records kept per query (the count goes on)
+
 struct SearchArgs {
 	MapView m;
 	pph::RolloutParams rp;
@@ -112,6 +124,8 @@ struct SearchArgs {
 	int directCount;   // rows kernel: the first `directCount` queries of the hand-out order are not its own (they run one per wave)
 	size_t cells;
 	int64_t fieldElems; // floats per query in costFields (8 x 8-tiled obstacle-heuristic field)
+	GuardRec* guardLog; // [queries][kGuardLogCap], nullptr: no log (throughput planners)
+	int* guardCount;    // [queries]
 };
 
 struct DevResult {
@@ -179,6 +193,25 @@ __device__ inline int write_path(const Node* nodes, int solutionNode, PathRec* o
 		k = nd.parent;
 	}
 	return depth;
+}
+
+__device__ __forceinline__ void guard_log(const SearchArgs& A, int q, int parent, int prim, int kind, double length, int ix, int iy, int it)
+{
+	if (!A.guardLog)
+		return;
+	const int pos = atomicAdd(A.guardCount + q, 1);
+	if (pos < kGuardLogCap) {
+		GuardRec r;
+		r.parent = parent;
+		r.prim = (int16_t)prim;
+		r.kind = (int16_t)kind;
+		r.length = length;
+		r.ix = ix;
+		r.iy = iy;
+		r.it = it;
+		r.pad = 0;
+		A.guardLog[(size_t)q * kGuardLogCap + pos] = r;
+	}
 }
 
 enum { PH_POP = 0, PH_LOAD, PH_HEUR, PH_CHILD, PH_DUP, PH_INSERT, PH_WRITE, PH_RS, PH_COUNT };
@@ -657,7 +690,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 				a.backward = A.prims.backward[p];
 				child = a.interpolate_sc(1.0, cs, cc);
 				int ix, iy, it;
-				lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
+				const bool onLine = discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+				lanePathChecks += (long long)onLine << kGuardShift;
+				if (onLine) // logged at once (nothing kept live across the march): if the arc gets truncated this entry is moot, and a
+					guard_log(A, q, ni, p, 1, a.length, ix, iy, it); // mismatch on it only sends the query to the CPU reference needlessly
 				PP_STAMP(PH_HEUR); // [diagnostic: endpoint]
 				// look-ups of the full-length child are issued before the validity march so that their
 				// latency overlaps it (they are redone only when the arc gets truncated)
@@ -695,7 +731,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 					// PathConstantSteer::Truncate, paths/path_constant_steer.cpp:16-20
 					child = a.interpolate_sc((double)lastValidRatio, cs, cc);
 					a.length *= (double)lastValidRatio;
-					lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
+					const bool onLineT = discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+					lanePathChecks += (long long)onLineT << kGuardShift;
+					if (onLineT)
+						guard_log(A, q, ni, p, 1, a.length, ix, iy, it); // the truncated child is the one that counts
 					if (ix == pix && iy == piy && it == pit)
 						ok = false;
 					else {
@@ -941,7 +980,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
 						const Pose child = path.interpolate(1.0);
 						int ix, iy, it;
-						lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
+						const bool onLineR = discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
+						lanePathChecks += (long long)onLineR << kGuardShift;
+						if (onLineR)
+							guard_log(A, q, ni, word, 2, path.length, ix, iy, it);
 						const double voro = voronoi_cost(m, path, A.rp.voroDiagRes, A.rp.voronoiMult);
 						const double cost = pathAndSwitchingCosts + voro;
 						uint32_t key;
@@ -1155,6 +1197,8 @@ struct pp_planner {
 	int searchRows = 0;                     // rows (= search buffer slots) this planner runs with
 	bool rowsKernel = false;                // four-queries-per-wave kernel (throughput) vs one query per wave (latency)
 	int compactBelow = 0;                   // first pass: a wave with an empty queue and <= this many busy rows re-queues them
+	GuardRec* guardLog = nullptr;           // [maxBatch][kGuardLogCap] lattice-line children (one-query-per-wave planners only)
+	int* guardCount = nullptr;              // [maxBatch]
 	PathRec* paths = nullptr;               // [maxBatch][maxPath] solution paths, goal first
 	int maxPath = 0;
 	double *dStarts = nullptr, *dGoals = nullptr;
@@ -1272,7 +1316,7 @@ void free_planner(pp_planner* p)
 	for (void* q : postPtrs)
 		if (q)
 			(void)hipFree(q);
-	void* ptrs[] = { p->bandMeta, p->bands, p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->guardLog, p->guardCount, p->bandMeta, p->bands, p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -1501,6 +1545,10 @@ static int create_planner(pp_map* map, const pp_hybrid_params* params, int32_t m
 	alloc((void**)&p->paths, B * (size_t)A.maxPath * sizeof(PathRec));
 	alloc((void**)&p->rsLogs, B * kRsLogCap * sizeof(RsLogEntry));
 	alloc((void**)&p->results, B * sizeof(DevResult));
+	if (!p->rowsKernel) { // the lattice-line log of pp_planner_certify_lattice: planners that keep the tree per query
+		alloc((void**)&p->guardLog, B * (size_t)kGuardLogCap * sizeof(GuardRec));
+		alloc((void**)&p->guardCount, B * 4);
+	}
 	alloc((void**)&p->prof, (forPipeline ? 1 : B) * PH_COUNT * sizeof(unsigned long long));
 	alloc((void**)&p->dStarts, B * 24);
 	alloc((void**)&p->dGoals, B * 24);
@@ -1544,6 +1592,8 @@ static int create_planner(pp_map* map, const pp_hybrid_params* params, int32_t m
 		return pph::hip_fail(e, "planner allocation");
 	}
 	A.heur.table = p->table;
+	A.guardLog = p->guardLog;
+	A.guardCount = p->guardCount;
 	p->nextQuery = p->wfError + 2;
 	p->nh.nx = dims[0];
 	*out = p;
@@ -1643,6 +1693,8 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		planner->startAfter = nullptr;
 	}
 	PP_HIP_TRY(hipMemsetAsync(planner->wfError, 0, 32, s)); // the step's only fill: every counter of every kernel
+	if (planner->guardCount)
+		PP_HIP_TRY(hipMemsetAsync(planner->guardCount, 0, (size_t)n_queries * 4, s));
 	PP_HIP_TRY(hipEventRecord(planner->e0, s));
 	// the rows kernel hands the queries out longest-first (order written by the wavefront kernel's last workgroup)
 	static const bool lpt = !(getenv("PP_SEARCH_ORDER") && getenv("PP_SEARCH_ORDER")[0] == '0');
@@ -1822,22 +1874,26 @@ int pp_planner_debug_node_actions(pp_planner* planner, int32_t q, int32_t max_no
 	return PP_OK;
 }
 
-/// SURVEY 7.3 H2 as a contract.  Every constant-steer child's pose is recomputed on the HOST with the C library the reference links
-/// (glibc sin / cos), along its own chain of ancestors from the start pose -- the arithmetic the reference performs for that node
-/// (KinematicBicycleModel::ConstantSteer, models/kinematic_bicycle_model.cpp:5-32, through PathConstantSteer::Interpolate with the
-/// stored, possibly truncated, length) -- and discretised (HybridAStar::DiscretizePose, algo/hybrid_a_star.h:104-111).  A node whose
-/// cell differs from the cell of the device's pose is a place where this libm and glibc disagree about a lattice boundary:
-/// n_cell_mismatches == 0 certifies every discrete pose of the query's search tree.  Needs the tree, i.e. a planner of the
-/// one-query-per-wave kind (max_batch <= 64 or PP_SEARCH_ROWS=0); queries of a throughput planner or pipeline that report
-/// n_lattice_boundary_hits > 0 are re-planned on such a planner (same kernels' device code, same results) and certified there.
-int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_nodes_checked, int32_t* n_cell_mismatches, double* max_pose_difference)
+/// SURVEY 7.3 H2 as a contract.  The search kernel flags every child whose DiscretizePose quotient lies within 1e-9 cells of a lattice
+/// line (n_lattice_boundary_hits) -- the only poses a last-bit difference between this libm and glibc could put into another cell
+/// (pose differences are ~1e-15) -- and, on planners that keep the tree, logs them: parent node, primitive, arc length, the cell the
+/// device chose.  Here the host recomputes (i) every CREATED constant-steer node and (ii) every LOGGED constant-steer child with the
+/// C library the reference links (glibc sin / cos), each along its own chain of ancestors from the start pose -- the arithmetic the
+/// reference performs (KinematicBicycleModel::ConstantSteer, models/kinematic_bicycle_model.cpp:5-32, through
+/// PathConstantSteer::Interpolate with the stored, possibly truncated, length) -- and discretises it (HybridAStar::DiscretizePose,
+/// algo/hybrid_a_star.h:104-111).  n_cell_mismatches: recomputed cells that differ from the device's.  n_unverified: flagged events
+/// that cannot be recomputed here (a Reeds-Shepp child on a lattice line; log entries beyond the 64 kept per query).
+/// Both 0 certifies the query's discrete outputs against the reference's arithmetic; else: hand the query to the CPU reference.
+/// Needs the tree, i.e. a planner of the one-query-per-wave kind (max_batch <= 64 or PP_SEARCH_ROWS=0); queries of a throughput planner
+/// or pipeline that report n_lattice_boundary_hits > 0 are re-planned on such a planner (same device code, same results) first.
+int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_checked, int32_t* n_cell_mismatches, int32_t* n_unverified, double* max_pose_difference)
 {
 	if (!planner || q < 0 || q >= planner->lastBatch || (int)planner->hostResults.size() <= q) {
 		set_error("no fetched result for this query (call pp_planner_fetch_results first)");
 		return PP_ERR_INVALID;
 	}
-	if (planner->rowsKernel) {
-		set_error("the search tree is kept per query by the one-query-per-wave kernel only (PP_SEARCH_ROWS=0 or max_batch <= 64)");
+	if (planner->rowsKernel || !planner->guardLog) {
+		set_error("the search tree and the lattice-line log are kept per query by the one-query-per-wave kernel only (PP_SEARCH_ROWS=0 or max_batch <= 64)");
 		return PP_ERR_INVALID;
 	}
 	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
@@ -1845,6 +1901,12 @@ int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_nodes_
 	std::vector<Node> nodes((size_t)(n > 0 ? n : 0));
 	if (n > 0)
 		PP_HIP_TRY(hipMemcpy(nodes.data(), planner->nodes + (size_t)q * planner->maxNodes, (size_t)n * sizeof(Node), hipMemcpyDeviceToHost));
+	int nLog = 0;
+	PP_HIP_TRY(hipMemcpy(&nLog, planner->guardCount + q, 4, hipMemcpyDeviceToHost));
+	const int kept = nLog < kGuardLogCap ? nLog : kGuardLogCap;
+	std::vector<GuardRec> log((size_t)kept);
+	if (kept > 0)
+		PP_HIP_TRY(hipMemcpy(log.data(), planner->guardLog + (size_t)q * kGuardLogCap, (size_t)kept * sizeof(GuardRec), hipMemcpyDeviceToHost));
 	const SearchArgs& A = planner->args;
 	auto wrap = [](double t) { // geometry/2dplane.h:36-45
 		while (t > M_PI)
@@ -1853,13 +1915,33 @@ int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_nodes_
 			t += 2 * M_PI;
 		return t;
 	};
-	auto cell = [&](double x, double y, double t, int c[3]) { // hybrid_a_star.h:104-111 (x86 conversions; the bins before WrapTheta's aliasing)
+	auto cell = [&](double x, double y, double t, int c[3]) { // hybrid_a_star.h:104-111 (x86 conversions), Pose2<int>::WrapTheta's aliasing (Appendix A Q6) when the planner models it
 		c[0] = (int)(x / A.rp.spatialRes);
 		c[1] = (int)(y / A.rp.spatialRes);
-		c[2] = (int)(wrap(t) / A.rp.angularRes);
+		int it = (int)(wrap(t) / A.rp.angularRes);
+		if (A.rp.headingAlias) {
+			while ((double)it > M_PI)
+				it = (int)((double)it - 2 * M_PI);
+			while ((double)it < -M_PI)
+				it = (int)((double)it + 2 * M_PI);
+		}
+		c[2] = it;
+	};
+	auto steer = [&](double& x, double& y, double& t, int prim, double length) { // kinematic_bicycle_model.cpp:5-32 with beta = 0
+		const double kappa = A.prims.kappa[prim];
+		const double dist = A.prims.backward[prim] ? -length : length;
+		if (std::fabs(kappa) > 1e-9) {
+			const double t0 = t;
+			t += dist * kappa;
+			x += 1 / kappa * (std::sin(t) - std::sin(t0));
+			y += 1 / kappa * (-std::cos(t) + std::cos(t0));
+		} else {
+			x += dist * std::cos(t);
+			y += dist * std::sin(t);
+		}
 	};
 	std::vector<double> hx((size_t)n), hy((size_t)n), ht((size_t)n);
-	int checked = 0, bad = 0;
+	int checked = 0, bad = 0, unverified = nLog - kept;
 	double worst = 0.0;
 	for (int i = 0; i < n; i++) {
 		const Node& nd = nodes[(size_t)i];
@@ -1870,19 +1952,8 @@ int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_nodes_
 			ht[(size_t)i] = nd.t;
 			continue;
 		}
-		const size_t p = (size_t)nd.parent;
-		const double kappa = A.prims.kappa[a];
-		const double dist = A.prims.backward[a] ? -nd.length : nd.length;
-		double x = hx[p], y = hy[p], t = ht[p];
-		if (std::fabs(kappa) > 1e-9) { // kinematic_bicycle_model.cpp:22-26 with beta = 0
-			const double t0 = t;
-			t += dist * kappa;
-			x += 1 / kappa * (std::sin(t) - std::sin(t0));
-			y += 1 / kappa * (-std::cos(t) + std::cos(t0));
-		} else {
-			x += dist * std::cos(t);
-			y += dist * std::sin(t);
-		}
+		double x = hx[(size_t)nd.parent], y = hy[(size_t)nd.parent], t = ht[(size_t)nd.parent];
+		steer(x, y, t, a, nd.length);
 		hx[(size_t)i] = x;
 		hy[(size_t)i] = y;
 		ht[(size_t)i] = t;
@@ -1895,10 +1966,25 @@ int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_nodes_
 		const double d = std::fmax(std::fmax(std::fabs(x - nd.x), std::fabs(y - nd.y)), std::fabs(t - nd.t));
 		worst = d > worst ? d : worst;
 	}
-	if (n_nodes_checked)
-		*n_nodes_checked = checked;
+	for (const GuardRec& g : log) { // children on a lattice line, created or not
+		if (g.kind != 1 || g.parent < 0 || g.parent >= n || g.prim < 0 || g.prim >= A.prims.n) {
+			unverified++;
+			continue;
+		}
+		double x = hx[(size_t)g.parent], y = hy[(size_t)g.parent], t = ht[(size_t)g.parent];
+		steer(x, y, t, g.prim, g.length);
+		int ch[3];
+		cell(x, y, t, ch);
+		checked++;
+		if (ch[0] != g.ix || ch[1] != g.iy || ch[2] != g.it)
+			bad++;
+	}
+	if (n_checked)
+		*n_checked = checked;
 	if (n_cell_mismatches)
 		*n_cell_mismatches = bad;
+	if (n_unverified)
+		*n_unverified = unverified;
 	if (max_pose_difference)
 		*max_pose_difference = worst;
 	return PP_OK;

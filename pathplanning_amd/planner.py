@@ -572,11 +572,12 @@ class HybridAStarBatch:
                     path=smoothed if r.smoothing_status >= 0 else sampled)
 
     def certify_lattice(self, q):
-        """SURVEY 7.3 H2 as a contract (pp_planner_certify_lattice): every constant-steer node of query q's tree recomputed on the host with
-        glibc and discretised; returns (nodes checked, cell mismatches, largest pose difference).  One-query-per-wave planners only."""
-        a, b, d = C.c_int32(0), C.c_int32(0), C.c_double(0)
-        check(self.lib.pp_planner_certify_lattice(self.h, int(q), C.byref(a), C.byref(b), C.byref(d)))
-        return a.value, b.value, d.value
+        """SURVEY 7.3 H2 as a contract (pp_planner_certify_lattice): created nodes and logged lattice-line children of query q recomputed on
+        the host with glibc; returns (checked, cell mismatches, unverified events, largest pose difference).  mismatches == unverified == 0
+        certifies the query's discrete outputs.  One-query-per-wave planners only."""
+        a, b, c, d = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_double(0)
+        check(self.lib.pp_planner_certify_lattice(self.h, int(q), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
 
     def get_expanded_of(self, q):
         r = self._results[q]
