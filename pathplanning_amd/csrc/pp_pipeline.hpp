@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) k_pipe_scatter(int n, const int32_t* __re
 }
 
 constexpr int kPipeSearchStreams = 4;
-constexpr int kPipeWavefrontStreams = 2;
+constexpr int kPipeWavefrontStreams = 4; // at most; pp_pipeline::nWf of them are used (2 unless PP_PIPE_WF_STREAMS says otherwise)
 
 } // namespace
 
@@ -88,6 +88,7 @@ struct pp_pipeline {
 	double wfMs = 0, searchMs = 0, searchMaxMs = 0;
 	long long wfLaunches = 0, wfGoals = 0, searchLaunches = 0;
 	unsigned long long idleTicks = 12500ull; // idle loop passes of ~4 us: about 50 ms
+	int nWf = 2;      // wavefront streams in use: consecutive submissions' launches overlap (the tail of one under the head of the next)
 	int wfBlocks = 0; // workgroups per wavefront launch (<= the resident number): the wavefront kernel's share of the chip
 };
 
@@ -116,7 +117,7 @@ void free_pipeline(pp_pipeline* P)
 			if (t.b)
 				(void)hipEventDestroy(t.b);
 		}
-	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfCtl[0], P->wfCtl[1] };
+	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfWorkspace[2], P->wfWorkspace[3], P->wfCtl[0], P->wfCtl[1], P->wfCtl[2], P->wfCtl[3] };
 	for (void* q : dev)
 		if (q)
 			(void)hipFree(q);
@@ -230,7 +231,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	auto* P = new pp_pipeline();
 	P->capacity = capacity;
 	if (search_rows == 0)
-		search_rows = 2304; // measured optimum on MI355X (profiles/r03_pipeline_sweep.txt): beyond it the wavefront kernel, which needs the other CUs' registers, becomes the bottleneck
+		search_rows = 2560; // measured optimum on MI355X (profiles/r03_pipeline_sweep.txt): beyond it the wavefront kernel, which needs the other CUs' registers, becomes the bottleneck
 	if (int rc = create_planner(map, params, capacity, max_nodes_per_query, search_rows, log_expansions ? PlannerUse::PipelineLogged : PlannerUse::Pipeline, &P->pl)) {
 		delete P;
 		return rc;
@@ -249,7 +250,12 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		e = hipMalloc((void**)&P->waveAlive, (size_t)P->waves * 4);
 	if (e == hipSuccess)
 		e = hipMalloc((void**)&P->slotLists, P->slotListCap * 4);
-	for (int i = 0; i < kPipeWavefrontStreams && e == hipSuccess; i++) {
+	if (const char* v = getenv("PP_PIPE_WF_STREAMS")) {
+		const long x = strtol(v, nullptr, 10);
+		if (x >= 1 && x <= kPipeWavefrontStreams)
+			P->nWf = (int)x;
+	}
+	for (int i = 0; i < P->nWf && e == hipSuccess; i++) {
 		e = hipMalloc(&P->wfWorkspace[i], (size_t)pl->wfBytesPerSlot * pl->wfSlots);
 		if (e == hipSuccess)
 			e = hipMalloc((void**)&P->wfCtl[i], 32);
@@ -373,7 +379,7 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	hipStream_t const w = P->wfStream[P->nextWf];
 	int32_t* const wctl = P->wfCtl[P->nextWf];
 	void* const wws = P->wfWorkspace[P->nextWf];
-	P->nextWf = (P->nextWf + 1) % kPipeWavefrontStreams;
+	P->nextWf = (P->nextWf + 1) % P->nWf;
 	PP_HIP_TRY(hipMemcpyAsync(listDev, stage, (size_t)k * 4, hipMemcpyHostToDevice, P->ctlStream));
 	hipLaunchKernelGGL(k_pipe_scatter, dim3((k + 255) / 256), dim3(256), 0, P->ctlStream, k, listDev, starts_dev, goals_dev, seeds_dev, pl->dStarts, pl->dGoals, pl->dSeeds);
 	PP_HIP_TRY(hipGetLastError());
@@ -463,13 +469,13 @@ int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out,
 	*n_out = n;
 	timed_harvest(P);
 	// the wavefront kernels' error flags come over asynchronously; what an earlier poll asked for is looked at now
-	if (P->errStage[0] || P->errStage[1]) {
+	if (P->errStage[0] || P->errStage[1] || P->errStage[2] || P->errStage[3]) {
 		set_error("obstacle-heuristic open list exceeded its workspace");
 		return PP_ERR_CAPACITY;
 	}
 	if (P->nSubmitted > P->doneHead) {
 		PP_HIP_TRY(hipSetDevice(pl->map->ctx->device));
-		for (int i = 0; i < kPipeWavefrontStreams; i++)
+		for (int i = 0; i < P->nWf; i++)
 			PP_HIP_TRY(hipMemcpyAsync(P->errStage + i, P->wfCtl[i], 4, hipMemcpyDeviceToHost, P->ctlStream));
 		// waves that left on their own (no work for idleTicks) are replaced while queries are outstanding
 		const auto now = std::chrono::steady_clock::now();

@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             d[c + "_KB"] = max(d.get(c + "_KB", 0.0), v)
 res = {
     "_note": "HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, from two separate rocprofv3 --pmc passes "
-    "(FETCH_SIZE, then WRITE_SIZE) of `bench.py --steps 1 --warmup 0 --streams 1` (4096 queries per launch; 2^26 poses for "
+    "(FETCH_SIZE, then WRITE_SIZE) of `bench.py --mode lanes --steps 1 --warmup 0 --streams 1` (4096 queries per launch; 2^26 poses for "
     "k_check_states); largest launch of each kernel. The factor 2 on FETCH_SIZE is the gfx950 correction of "
     "MI355X_MICROARCH.md (HBM section); it was calibrated on k_check_states_fused (reads only the 4.19 MB distance grid, "
     "once per XCD L2 = 33.5 MB expected, FETCH_SIZE*1024 reports 16.9 MB) and k_check_states (writes 1 B/pose, "

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc_$TAG
 rm -rf $OUT && mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-	rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o run -- python3 bench.py --steps 1 --warmup 0 --streams 1 --no-cpu-baseline > $OUT/$c.log 2>&1
+	rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o run -- python3 bench.py --mode lanes --steps 1 --warmup 0 --streams 1 --no-cpu-baseline > $OUT/$c.log 2>&1
 	echo "pass $c done"
 done
 python3 tools/pmc_summarize.py $OUT
