@@ -207,6 +207,11 @@ def main():
         gather_all()
         return out, timings
 
+    # steps are accounting, not barriers: when a step is smaller than a submission (--batch 512 = one GPU's share of configs[3] at
+    # N = 8), one submission carries several steps' queries -- the arrays are tiled so that a submission stays one contiguous range
+    rep = max(1, args.submit_chunk // B) if pipeline_mode else 1
+    d_starts_rep, d_goals_rep, d_seeds_rep = (d_starts.repeat(rep, 1), d_goals.repeat(rep, 1), d_seeds.repeat(rep)) if rep > 1 else (d_starts, d_goals, d_seeds)
+
     def run_steps_pipeline(k):
         """k steps = k x B queries through the library's pipeline: submitted as slots are free, polled in completion order.  Returns the
         last step's results (by query index) and the sums over all k steps."""
@@ -218,10 +223,10 @@ def main():
         while done < total:
             if submitted < total:
                 free = pipe.free_slots()
-                off = submitted % B
-                want = min(B - off, args.submit_chunk)
+                off = submitted % (rep * B)
+                want = min(rep * B - off, args.submit_chunk, total - submitted)
                 if free >= want:  # a submission is one wavefront launch: never a handful of goals (a launch lasts at least one goal's 20 ms)
-                    first, kk = pipe.submit_dev(d_starts, d_goals, d_seeds, n=want, offset=off)
+                    first, kk = pipe.submit_dev(d_starts_rep, d_goals_rep, d_seeds_rep, n=want, offset=off)
                     if base is None:
                         base = first
                     submitted += kk

@@ -328,9 +328,11 @@ int pp_pipeline_destroy(pp_pipeline* P)
 	(void)hipMemcpyAsync(&P->ctl->stop, &one, 4, hipMemcpyHostToDevice, P->ctlStream);
 	(void)hipStreamSynchronize(P->ctlStream);
 	for (hipStream_t s : P->wfStream)
-		(void)hipStreamSynchronize(s);
+		if (s)
+			(void)hipStreamSynchronize(s);
 	for (hipStream_t s : P->searchStream)
-		(void)hipStreamSynchronize(s);
+		if (s)
+			(void)hipStreamSynchronize(s);
 	free_pipeline(P);
 	return PP_OK;
 }
@@ -479,7 +481,7 @@ int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out,
 			PP_HIP_TRY(hipMemcpyAsync(P->errStage + i, P->wfCtl[i], 4, hipMemcpyDeviceToHost, P->ctlStream));
 		// waves that left on their own (no work for idleTicks) are replaced while queries are outstanding
 		const auto now = std::chrono::steady_clock::now();
-		if (std::chrono::duration_cast<std::chrono::milliseconds>(now - P->lastLaunch).count() >= 20)
+		if (std::chrono::duration_cast<std::chrono::milliseconds>(now - P->lastLaunch).count() >= 100) // (twice the waves' own idle time-out)
 			return pipe_launch_search(P);
 	}
 	return PP_OK;

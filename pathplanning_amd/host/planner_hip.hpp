@@ -843,6 +843,90 @@ struct RRTStarParameters {
 	double radiusGamma = 0.0;
 };
 
+/// HybridAStar::SearchPath's search stage for a STREAM of queries (include/pp_hip.h: pp_pipeline_*): queries are submitted as they
+/// come -- up to `capacity` in flight -- and results polled in completion order; per query they are what HybridAStar::SearchPath
+/// finds (same device code).  The scheduling that keeps the GPU full lives in the library, not in the caller.
+class HybridAStarPipeline {
+public:
+	struct Result {
+		uint64_t ticket = 0;
+		Status status = Status::Failure;
+		double cost = 0.0;
+		int numExpanded = 0, numPathNodes = 0, latticeBoundaryHits = 0;
+	};
+	explicit HybridAStarPipeline(const HybridAStar::SearchParameters& p, int capacity = 24576, int maxNodes = 81920, int searchRows = 0) :
+		m_param(p), m_capacity(capacity), m_maxNodes(maxNodes), m_searchRows(searchRows) { }
+	HybridAStarPipeline(const HybridAStarPipeline&) = delete;
+	HybridAStarPipeline& operator=(const HybridAStarPipeline&) = delete;
+	~HybridAStarPipeline()
+	{
+		if (m_pipe)
+			pp_pipeline_destroy(m_pipe);
+	}
+	bool Initialize(const Ref<StateValidatorOccupancyMap>& validator)
+	{
+		if (!validator || !validator->GetStateSpace())
+			return false;
+		m_validator = validator;
+		if (validator->GetOccupancyMap()->FieldsOutdated())
+			validator->GetOccupancyMap()->BuildFields(20.0f, 30.0f);
+		pp_hybrid_params hp { m_param.wheelbase, m_param.minTurningRadius, m_param.directionSwitchingCost, m_param.reverseCostMultiplier,
+			m_param.forwardCostMultiplier, m_param.voronoiCostMultiplier, m_param.numGeneratedMotion, m_param.spatialResolution, m_param.angularResolution, 1, 1 };
+		if (m_pipe) {
+			pp_pipeline_destroy(m_pipe);
+			m_pipe = nullptr;
+		}
+		if (pp_pipeline_create(validator->Device(), &hp, m_capacity, m_maxNodes, m_searchRows, 0, &m_pipe))
+			return false;
+		return pp_planner_set_nonholo_table(pp_pipeline_planner(m_pipe), nullptr) == 0;
+	}
+	/// takes a prefix of the queries (as many as there are free slots) and returns how many; `tickets` (optional) gets their ids
+	int Submit(const std::vector<Pose2d>& starts, const std::vector<Pose2d>& goals, const std::vector<uint64_t>& seeds, std::vector<uint64_t>* tickets = nullptr)
+	{
+		static_assert(sizeof(Pose2d) == 24, "Pose2d is three contiguous doubles");
+		const int n = (int)std::min(starts.size(), std::min(goals.size(), seeds.size()));
+		if (!m_pipe || n == 0)
+			return 0;
+		m_validator->Device(); // pushes map edits / tunables
+		std::vector<uint64_t> t((size_t)n);
+		int32_t taken = 0;
+		ppCheck(pp_pipeline_submit(m_pipe, n, &starts[0].position.v[0], &goals[0].position.v[0], seeds.data(), t.data(), &taken));
+		if (tickets)
+			tickets->assign(t.begin(), t.begin() + taken);
+		return taken;
+	}
+	/// completed queries so far (never blocks); their slots are free again
+	int Poll(std::vector<Result>& out, int maxResults = 4096)
+	{
+		out.clear();
+		if (!m_pipe)
+			return 0;
+		std::vector<uint64_t> t((size_t)maxResults);
+		std::vector<pp_query_result> r((size_t)maxResults);
+		int32_t n = 0;
+		ppCheck(pp_pipeline_poll(m_pipe, maxResults, t.data(), r.data(), 1, &n));
+		for (int i = 0; i < n; i++) {
+			Result x;
+			x.ticket = t[(size_t)i];
+			x.status = r[(size_t)i].status == 0 ? Status::Success : Status::Failure;
+			x.cost = r[(size_t)i].cost;
+			x.numExpanded = r[(size_t)i].n_expanded;
+			x.numPathNodes = r[(size_t)i].n_path;
+			x.latticeBoundaryHits = r[(size_t)i].n_lattice_boundary_hits;
+			out.push_back(x);
+		}
+		return n;
+	}
+	int InFlight() const { return m_pipe ? pp_pipeline_in_flight(m_pipe) : 0; }
+	int FreeSlots() const { return m_pipe ? pp_pipeline_free_slots(m_pipe) : 0; }
+
+private:
+	HybridAStar::SearchParameters m_param;
+	int m_capacity, m_maxNodes, m_searchRows;
+	Ref<StateValidatorOccupancyMap> m_validator;
+	pp_pipeline* m_pipe = nullptr;
+};
+
 /// RRT<Point2d, 2> / RRTStar<Point2d, 2> with PathConnectionR2; validator == nullptr is StateValidatorFree.
 template <bool kStar, typename Params>
 class RRTR2Hip : public PathPlannerR2Base {

@@ -106,8 +106,52 @@ static void TestPaths()
 	std::printf("paths: Reeds-Shepp connections reach their goals, IsPathValid over RS / SE2 / constant-steer paths\n");
 }
 
+// the streaming form of the same planner: 40 queries through a pipeline of 16 slots; every result must be what SearchPath gives
+static void TestPipeline()
+{
+	std::array<Pose2d, 2> bounds = { Pose2d(-10, -10, -M_PI), Pose2d(10, 10, M_PI) };
+	Ref<StateSpaceSE2> stateSpace = makeRef<StateSpaceSE2>(bounds);
+	Ref<OccupancyMap> map = makeRef<OccupancyMap>(0.1f);
+	Ref<StateValidatorOccupancyMap> validator = makeRef<StateValidatorOccupancyMap>(stateSpace, map);
+	HybridAStar single;
+	assert(single.Initialize(validator));
+	HybridAStarPipeline pipe(HybridAStar::SearchParameters(), /*capacity=*/16, /*maxNodes=*/32768, /*searchRows=*/8);
+	assert(pipe.Initialize(validator));
+	const int n = 40;
+	std::vector<Pose2d> starts, goals;
+	std::vector<uint64_t> seeds;
+	std::vector<double> cost((size_t)n);
+	for (int i = 0; i < n; i++) {
+		starts.push_back(Pose2d(-8.0 + 0.37 * i, -7.5 + 0.21 * i, 0.1 * i));
+		goals.push_back(Pose2d(8.0 - 0.29 * i, 7.0 - 0.33 * i, 0.78 - 0.05 * i));
+		seeds.push_back(100 + i);
+		single.SetInitState(starts.back());
+		single.SetGoalState(goals.back());
+		single.SetSeed(seeds.back());
+		assert(single.SearchPath() == Status::Success);
+		cost[(size_t)i] = single.GetGraphSearchOptimalCost();
+	}
+	int submitted = 0, done = 0;
+	std::vector<HybridAStarPipeline::Result> res;
+	while (done < n) {
+		if (submitted < n && pipe.FreeSlots() > 0) {
+			std::vector<Pose2d> s(starts.begin() + submitted, starts.end()), g(goals.begin() + submitted, goals.end());
+			std::vector<uint64_t> sd(seeds.begin() + submitted, seeds.end());
+			submitted += pipe.Submit(s, g, sd);
+		}
+		pipe.Poll(res);
+		for (const auto& r : res) { // tickets count submissions: ticket t is query t
+			assert(r.ticket < (uint64_t)n && r.status == Status::Success && r.cost == cost[(size_t)r.ticket]);
+			done++;
+		}
+	}
+	assert(pipe.InFlight() == 0 && pipe.FreeSlots() == 16);
+	std::printf("pipeline: %d queries through 16 slots, costs equal to SearchPath's\n", n);
+}
+
 int main()
 {
+	TestPipeline();
 	TestHybridAStar();
 	TestRRT();
 	TestPaths();

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 2: ONE Hybrid-A* query on a 512 x 512 map ((-23.04,-23.04,0) -> (23.04,23.04,0), seed
-12345), P = 10 (reference default) and P = 74 (numGeneratedMotion = 37, the reference-reachable count next to "72").
+12345), P = 10 (reference default), P = 74 (numGeneratedMotion = 37, the reference-reachable count next to "72") and P = 72 through
+an explicit table of 36 steering angles (pp_planner_set_primitives; the oracle gets the same list in place of m_deltas).
 Latency of the device path (wavefront + graph search) beside the CPU oracle on one core."""
 import os
 import sys
@@ -25,16 +26,24 @@ ow.set_pathcost(m["path_cost"])
 start = np.array([[-23.04, -23.04, 0.0]])
 goal = np.array([[23.04, 23.04, 0.0]])
 seeds = np.array([12345], dtype=np.uint64)
-for ngm in (5, 37):
-    P = pa.HybridAStarSearchParameters(num_generated_motion=ngm)
-    planner = pa.HybridAStarBatch(val, P, max_batch=1, max_nodes=65536)
+import math  # noqa: E402
+for ngm in (5, 37, "72 explicit"):
+    P = pa.HybridAStarSearchParameters(num_generated_motion=ngm if isinstance(ngm, int) else 5)
+    planner = pa.HybridAStarBatch(val, P, max_batch=1, max_nodes=131072)
+    deltas = None
+    if not isinstance(ngm, int):
+        delta_max = math.atan(P.wheelbase / P.min_turning_radius)
+        deltas = np.linspace(-delta_max, delta_max, 36)
+        planner.set_primitives(deltas)
     planner.initialize()
     for it in range(3):
         t = time.time()
         res = planner.search_batch(start, goal, seeds)
         wall = (time.time() - t) * 1e3
         wf, se = planner.last_timings()
-    h = O.Hybrid(ow, O.params_array(num_generated_motion=ngm), table=planner.nonholo_table())
+    h = O.Hybrid(ow, O.params_array(num_generated_motion=ngm if isinstance(ngm, int) else 5), table=planner.nonholo_table())
+    if deltas is not None:
+        h.set_deltas(deltas)
     t = time.time()
     r = h.search(start[0], goal[0], 12345)
     cpu = (time.time() - t) * 1e3
