@@ -262,6 +262,7 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 	__shared__ uint8_t c_valid[kSlots];
 	__shared__ int16_t c_action[kSlots];
 	__shared__ int s_rsChecks;
+	__shared__ double s_rsPre[24]; // rs::Path::make_prefix of the Reeds-Shepp attempt (23 doubles)
 #if PP_SEARCH_DIST_WINDOW
 	__shared__ __attribute__((aligned(16))) float s_win[kDistWinElems]; // obstacle distances around the expanded node (pp_device.hpp: DistWindow)
 #endif
@@ -973,18 +974,20 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 					path.length = path.seg.length * A.rmin; // PathSegment::GetLength
 					float lastRatio;
 					int checks = 0;
-					const bool valid = is_path_valid(m, path, path.init, lastRatio, checks);
+					path.make_prefix(s_rsPre); // (see k_hybrid_search_rows)
+					const rs::PrefixedPath ppath = { path, s_rsPre, path.length };
+					const bool valid = is_path_valid(m, ppath, path.init, lastRatio, checks);
 					c_valid[kRsSlot] = 0;
 					s_rsChecks = checks;
 					if (valid) {
 						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
-						const Pose child = path.interpolate(1.0);
+						const Pose child = ppath.interpolate(1.0);
 						int ix, iy, it;
 						const bool onLineR = discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it);
 						lanePathChecks += (long long)onLineR << kGuardShift;
 						if (onLineR)
 							guard_log(A, q, ni, word, 2, path.length, ix, iy, it);
-						const double voro = voronoi_cost(m, path, A.rp.voroDiagRes, A.rp.voronoiMult);
+						const double voro = voronoi_cost(m, ppath, A.rp.voroDiagRes, A.rp.voronoiMult);
 						const double cost = pathAndSwitchingCosts + voro;
 						uint32_t key;
 						if (A.ks.pack(ix, iy, it, key)) {

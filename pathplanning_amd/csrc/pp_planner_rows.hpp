@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		uint32_t c_key[kS], c_state[kS], f_for[kS];
 		float c_d0[kS]; // obstacle distance at the child's pose (< 0: invalid state), see Node::dist0
 		int rsChecks[kRowsPerWave];
+		double rsPre[kRowsPerWave][24]; // rs::Path::make_prefix of the row's Reeds-Shepp attempt (23 doubles)
 		int16_t c_action[kS];
 		uint8_t c_flags[kS], c_valid[kS]; // flags: 1 = valid child, 2 = an earlier child of the batch shares its cell
 	};
@@ -1064,15 +1065,20 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 					path.length = path.seg.length * A.rmin; // PathSegment::GetLength
 					float lastRatio;
 					int checks = 0;
-					const bool valid = is_path_valid(m, path, path.init, lastRatio, checks);
+					// every sample of the march continues from the stored start of its motion instead of walking the word from its
+					// beginning (same operations on the same values: rs::Path::make_prefix)
+					double* const pre = W.rsPre[lane >> 4];
+					path.make_prefix(pre);
+					const rs::PrefixedPath ppath = { path, pre, path.length };
+					const bool valid = is_path_valid(m, ppath, path.init, lastRatio, checks);
 					c_valid[sb + kRowRs] = 0;
 					s_rsChecks[lane >> 4] = checks;
 					if (valid) {
 						const double pathAndSwitchingCosts = (double)rs::compute_cost(path.seg, A.rmin, A.rsRev, A.rsFwd, A.rsSw); // PathReedsShepp::ComputeCost
-						const Pose child = path.interpolate(1.0);
+						const Pose child = ppath.interpolate(1.0);
 						int ix, iy, it;
 						lanePathChecks += (long long)discretize_pose(child, A.rp.lat, A.rp.headingAlias, ix, iy, it) << kGuardShift;
-						const double voro = voronoi_cost(m, path, A.rp.voroDiagRes, A.rp.voronoiMult);
+						const double voro = voronoi_cost(m, ppath, A.rp.voroDiagRes, A.rp.voronoiMult);
 						const double cost = pathAndSwitchingCosts + voro;
 						uint32_t key;
 						if (A.ks.pack(ix, iy, it, key)) {

@@ -372,6 +372,59 @@ namespace rs {
 			}
 			return interp;
 		}
+		/// Interpolate's chain, computed once.  PathReedsShepp::Interpolate (paths/path_reeds_shepp.cpp:12-47) walks the motions from m_init
+		/// for EVERY sample: the motions before the one that contains the sample are applied in full (motionRatio clamps to 1.0, and
+		/// len * 1.0 == len), i.e. with the same operands every time.  make_prefix stores, per motion, the pose it starts from and the
+		/// length before it (4 doubles each, then the end pose: kPrefixDoubles in all); interpolate_prefix continues from there with the one
+		/// partial motion -- the same operations on the same values as interpolate(), hence the same bits, at a fifth of the trigonometry
+		/// for a five-motion word.  The validity march of the search kernels' Reeds-Shepp child (one lane, ~30 samples) uses it.
+		static constexpr int kPrefixDoubles = 4 * kNumMotion + 3;
+		PPD_INLINE void make_prefix(double* pre) const
+		{
+			Pose interp = init;
+			double len = 0;
+			for (int i = 0; i < kNumMotion; i++) {
+				pre[4 * i] = interp.x;
+				pre[4 * i + 1] = interp.y;
+				pre[4 * i + 2] = interp.t;
+				pre[4 * i + 3] = len;
+				if (!motion_valid(seg, i))
+					continue; // (entries behind the last motion are never read)
+				const double motionLength = seg.len[i] * rmin;
+				if (motionLength == 0)
+					continue;
+				const double motionRatio = 1.0;
+				if (seg.steer[i] == kStraight)
+					interp = straight(interp, seg.dir[i], seg.len[i] * motionRatio);
+				else
+					interp = turn(interp, seg.dir[i], seg.steer[i], seg.len[i] * motionRatio);
+				len += motionLength;
+			}
+			pre[4 * kNumMotion] = interp.x;
+			pre[4 * kNumMotion + 1] = interp.y;
+			pre[4 * kNumMotion + 2] = interp.t;
+		}
+		PPD_INLINE Pose interpolate_prefix(const double* pre, double ratio) const
+		{
+			const double totalLength = length;
+			if (totalLength == 0)
+				return init;
+			for (int i = 0; i < kNumMotion; i++) {
+				if (!motion_valid(seg, i))
+					break;
+				const double motionLength = seg.len[i] * rmin;
+				if (motionLength == 0)
+					continue;
+				const double len = pre[4 * i + 3];
+				if (len + motionLength >= ratio * totalLength) { // the motion at which interpolate() leaves its loop
+					double motionRatio = (ratio * totalLength - len) / motionLength;
+					motionRatio = motionRatio < 1.0 ? motionRatio : 1.0;
+					const Pose from = { pre[4 * i], pre[4 * i + 1], pre[4 * i + 2] };
+					return seg.steer[i] == kStraight ? straight(from, seg.dir[i], seg.len[i] * motionRatio) : turn(from, seg.dir[i], seg.steer[i], seg.len[i] * motionRatio);
+				}
+			}
+			return { pre[4 * kNumMotion], pre[4 * kNumMotion + 1], pre[4 * kNumMotion + 2] }; // every motion in full
+		}
 		/// PathReedsShepp::Truncate, paths/path_reeds_shepp.cpp:49-93: returns m_final.  The reference means to drop the
 		/// motions behind the cut but resets `m_motions[i]` -- the motion that CONTAINS the cut -- instead of `[ii]` whenever
 		/// a later slot exists (i < 4); `q11` = true reproduces that, false drops the later ones.
@@ -489,6 +542,14 @@ namespace rs {
 		}
 		return bestWord;
 	}
+
+/// a Path seen through its prefix (Path::make_prefix): what is_path_valid / voronoi_cost need -- `length` and `interpolate`
+struct PrefixedPath {
+	const Path& path;
+	const double* pre;
+	double length;
+	PPD_INLINE Pose interpolate(double ratio) const { return path.interpolate_prefix(pre, ratio); }
+};
 
 } // namespace rs
 } // namespace ppd
