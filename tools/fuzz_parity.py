@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""One-off parity sweep (GPU + oracle): random maps and queries through both search kernels; every query must agree with
-the oracle in status, expansion sequence, node / RNG / check counters, cost and path."""
+"""One-off parity sweep (GPU + oracle): random maps and queries through both search kernels and through the streaming pipeline
+(field slots recycled six times); every query must agree with the oracle in status, expansion sequence, node / RNG / check counters,
+cost and path."""
+import time
 import os
 import sys
 
@@ -35,4 +37,34 @@ for cells, nobs, seed in ((256, 6, 11), (512, 14, 12), (384, 20, 13)):
         print("map %dx%d seed %d, kernel rows=%s: %d queries identical to the oracle (%d solved, max %d expansions)" % (
             cells, cells, seed, rows, N, n_ok, max(r.n_expanded for r in res)))
         planner.close()
+    # the same queries through the streaming pipeline: N / 6 slots, so every slot is used about six times
+    os.environ.pop("PP_SEARCH_ROWS", None)
+    os.environ.pop("PP_SEARCH_SUSPEND_AFTER", None)
+    pipe = pa.HybridAStarPipeline(val, capacity=max(8, N // 6), max_nodes=65536, search_rows=32, log_expansions=True)
+    pipe.initialize()
+    h = O.Hybrid(w, O.params_array(), table=pipe.nonholo_table())
+    index_of, nxt, done, t0, solved = {}, 0, 0, time.time(), 0
+    while done < N:
+        if nxt < N and pipe.free_slots() > 0:
+            for i, t in enumerate(pipe.submit(starts[nxt:], goals[nxt:], seeds[nxt:])):
+                index_of[int(t)] = nxt + i
+            nxt = len(index_of)
+        tickets, res = pipe.poll(256, release=False)
+        for i, t in enumerate(tickets):
+            q, g = index_of[int(t)], res[i]
+            r = h.search(starts[q], goals[q], int(seeds[q]))
+            assert g.status == r["status"] and g.n_expanded == len(r["expanded"]) and np.array_equal(pipe.get_expanded_of(int(t)), r["expanded"]), q
+            assert (g.n_nodes, g.n_rng_draws, g.n_rs_attempts, g.n_state_checks, g.n_path_checks) == (r["n_nodes"], r["n_rng_draws"], r["n_rs_attempts"], r["n_state_checks"], r["n_path_checks"]), q
+            if r["status"] == 0:
+                solved += 1
+                path = pipe.get_path_of(int(t))
+                assert abs(g.cost - r["cost"]) < 1e-5 and len(path["poses"]) == len(r["path_poses"]) and np.abs(path["poses"] - r["path_poses"]).max() < 1e-5, q
+            done += 1
+        if len(tickets):
+            pipe.release(tickets)
+        assert time.time() - t0 < 900, "pipeline stalled"
+    pipe.close()
+    total += N
+    ok += N
+    print("map %dx%d seed %d, pipeline (%d slots): %d queries identical to the oracle (%d solved)" % (cells, cells, seed, max(8, N // 6), N, solved))
 print("TOTAL %d/%d" % (ok, total))
