@@ -117,3 +117,42 @@ def test_pipeline_equals_the_batch_planner_and_restarts_after_idling():
     run(1000, n)
     pipe.close()
     batch.close()
+
+
+def test_pipeline_under_dribbling_submissions_and_short_idle_timeout(monkeypatch):
+    """The grid's waves leave when nothing is left to claim (or after PP_PIPE_IDLE_MS without work) and every submission launches the grid
+    again: here with a 1 ms idle time-out, 8 slots, 2 waves and queries arriving one to three at a time with pauses, so that waves leave
+    and re-enter constantly (the hand-back of a wave index races with the next submission's launch).  Every result must still be the
+    batch planner's, and nothing may stall."""
+    import pathplanning_amd as pa
+    monkeypatch.setenv("PP_PIPE_IDLE_MS", "1")
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    rng = np.random.RandomState(77)
+    n = 240
+    starts, goals = valid_random_poses(rng, w, n), valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 5000
+    batch = pa.HybridAStarBatch(val, max_batch=n, max_nodes=32768, search_rows=64)
+    batch.initialize()
+    want = batch.search_batch(starts, goals, seeds)
+    pipe = pa.HybridAStarPipeline(val, capacity=8, max_nodes=32768, search_rows=8)
+    pipe.initialize(batch.nonholo_table())
+    index_of, nxt, got = {}, 0, {}
+    t0 = time.time()
+    while len(got) < n:
+        if nxt < n and pipe.free_slots() > 0:
+            k = min(n - nxt, int(rng.randint(1, 4)), pipe.free_slots())
+            for i, t in enumerate(pipe.submit(starts[nxt:nxt + k], goals[nxt:nxt + k], seeds[nxt:nxt + k])):
+                index_of[int(t)] = nxt + i
+            nxt = len(index_of)
+            if rng.rand() < 0.3:
+                time.sleep(float(rng.uniform(0.0, 0.004)))  # longer than the idle time-out now and then
+        tickets, res = pipe.poll(16)
+        for i, t in enumerate(tickets):
+            got[index_of[int(t)]] = (res[i].status, res[i].n_expanded, res[i].n_nodes, res[i].cost)
+        assert time.time() - t0 < 240, "pipeline stalled: %d of %d" % (len(got), n)
+    for q in range(n):
+        s_, e_, nn_, c_ = got[q]
+        assert (s_, e_, nn_) == (want[q].status, want[q].n_expanded, want[q].n_nodes) and (s_ != 0 or c_ == want[q].cost), q
+    assert pipe.in_flight() == 0
+    pipe.close()
+    batch.close()
