@@ -212,6 +212,8 @@ def main():
     rep = max(1, args.submit_chunk // B) if pipeline_mode else 1
     d_starts_rep, d_goals_rep, d_seeds_rep = (d_starts.repeat(rep, 1), d_goals.repeat(rep, 1), d_seeds.repeat(rep)) if rep > 1 else (d_starts, d_goals, d_seeds)
 
+    backlog = []  # (ready, searching) samples of the last run_steps_pipeline
+
     def run_steps_pipeline(k):
         """k steps = k x B queries through the library's pipeline: submitted as slots are free, polled in completion order.  Returns the
         last step's results (by query index) and the sums over all k steps."""
@@ -220,6 +222,7 @@ def main():
         last = np.zeros(B, dtype=QUERY_RESULT_DTYPE)
         sums = dict(success=0, expansions=0, rs_attempts=0, rng_draws=0, state_checks=0, path_checks=0)
         base = None
+        backlog.clear()
         while done < total:
             if submitted < total:
                 free = pipe.free_slots()
@@ -231,6 +234,7 @@ def main():
                         base = first
                     submitted += kk
             tickets, res = pipe.poll_array(8192)
+            backlog.append(pipe.backlog())
             if len(tickets):
                 idx = (tickets - np.uint64(base)).astype(np.int64)
                 in_last = idx >= (k - 1) * B
@@ -451,7 +455,9 @@ def main():
             "roofline": roof,
             "roofline_per_kernel": roofs,
             "map_build": map_info,
-            **({"pipeline_kernel_timings": pipe_kernel, "run_totals": run_sums} if pipeline_mode else {}),
+            **({"pipeline_kernel_timings": pipe_kernel, "run_totals": run_sums,
+                "pipeline_backlog": dict(samples=len(backlog), ready_mean=float(np.mean([b[0] for b in backlog])), ready_p10=float(np.percentile([b[0] for b in backlog], 10)),
+                                         ready_max=int(max(b[0] for b in backlog)), searching_mean=float(np.mean([b[1] for b in backlog])), rows=pipe.search_rows)} if pipeline_mode else {}),
             "cpu_baseline": cpu,
         }
         print(json.dumps(out, default=lambda o: o.item() if hasattr(o, "item") else str(o)))

@@ -173,6 +173,7 @@ def load():
     L.pp_pipeline_release.argtypes = [vp, C.c_int32, vp]
     L.pp_pipeline_slot_of.argtypes = [vp, C.c_uint64]
     L.pp_pipeline_timings.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.pp_pipeline_backlog.argtypes = [vp, vp, vp]
     L.pp_pipeline_planner.argtypes = [vp]
     L.pp_pipeline_planner.restype = vp
     for f in ("pp_pipeline_capacity", "pp_pipeline_search_rows", "pp_pipeline_in_flight", "pp_pipeline_free_slots"):

@@ -67,6 +67,7 @@ struct pp_pipeline {
 	unsigned long long* submittedStage = nullptr; // ring of submission counts on their way to ctl->nSubmitted
 	int submittedStagePos = 0;
 	int32_t* errStage = nullptr; // copies of the wavefront error flags, refreshed by every poll
+	PipeCtl* ctlStage = nullptr; // copy of the device control block, refreshed by every poll (pp_pipeline_backlog reads the last one)
 	// streams
 	hipStream_t wfStream[kPipeWavefrontStreams] = {}, searchStream[kPipeSearchStreams] = {}, ctlStream = nullptr;
 	hipEvent_t evIngest = nullptr, evCtl = nullptr;
@@ -121,7 +122,7 @@ void free_pipeline(pp_pipeline* P)
 	for (void* q : dev)
 		if (q)
 			(void)hipFree(q);
-	void* host[] = { P->done, P->slotStage, P->submittedStage, P->errStage };
+	void* host[] = { P->done, P->slotStage, P->submittedStage, P->errStage, P->ctlStage };
 	for (void* q : host)
 		if (q)
 			(void)hipHostFree(q);
@@ -281,6 +282,8 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	if (e == hipSuccess)
 		e = hipHostMalloc((void**)&P->errStage, 64, hipHostMallocDefault);
 	if (e == hipSuccess)
+		e = hipHostMalloc((void**)&P->ctlStage, sizeof(PipeCtl), hipHostMallocDefault);
+	if (e == hipSuccess)
 		e = hipMemset(P->ctl, 0, sizeof(PipeCtl));
 	if (e == hipSuccess)
 		e = hipMemset(P->ready, 0, ring * 8);
@@ -294,6 +297,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	}
 	std::memset(P->done, 0, ring * sizeof(PipeDone));
 	std::memset(P->errStage, 0, 64);
+	std::memset(P->ctlStage, 0, sizeof(PipeCtl));
 	P->freeSlots.resize((size_t)capacity);
 	for (int i = 0; i < capacity; i++)
 		P->freeSlots[(size_t)i] = capacity - 1 - i; // slot 0 is handed out first
@@ -479,6 +483,7 @@ int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out,
 		PP_HIP_TRY(hipSetDevice(pl->map->ctx->device));
 		for (int i = 0; i < P->nWf; i++)
 			PP_HIP_TRY(hipMemcpyAsync(P->errStage + i, P->wfCtl[i], 4, hipMemcpyDeviceToHost, P->ctlStream));
+		PP_HIP_TRY(hipMemcpyAsync(P->ctlStage, P->ctl, sizeof(PipeCtl), hipMemcpyDeviceToHost, P->ctlStream));
 		// waves that left on their own (no work for idleTicks) are replaced while queries are outstanding
 		const auto now = std::chrono::steady_clock::now();
 		if (std::chrono::duration_cast<std::chrono::milliseconds>(now - P->lastLaunch).count() >= 100) // (twice the waves' own idle time-out)
@@ -531,6 +536,24 @@ int pp_pipeline_timings(pp_pipeline* P, double* wavefront_ms_total, int64_t* wav
 		*search_max_ms = P->searchMaxMs;
 	P->wfMs = P->searchMs = P->searchMaxMs = 0;
 	P->wfLaunches = P->wfGoals = P->searchLaunches = 0;
+	return PP_OK;
+}
+
+/// Where the queries in flight are, as of the copy of the control block an earlier poll asked for (asynchronous: a few hundred
+/// microseconds old): ready = fields built and waiting for a search row; searching = claimed by a row and not yet announced;
+/// the rest of pp_pipeline_in_flight() is still with the wavefront kernel (or completed and not yet polled).
+/// ready near 0 with rows to spare = the wavefront stage is the bottleneck; a long ready queue = the search grid is.
+int pp_pipeline_backlog(pp_pipeline* P, int64_t* ready, int64_t* searching)
+{
+	if (!P) {
+		set_error("null pipeline");
+		return PP_ERR_INVALID;
+	}
+	const PipeCtl c = *P->ctlStage;
+	if (ready)
+		*ready = (int64_t)(c.readyTail - c.readyHead);
+	if (searching)
+		*searching = (int64_t)(c.readyHead - c.doneTail);
 	return PP_OK;
 }
 

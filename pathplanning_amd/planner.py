@@ -697,6 +697,12 @@ class HybridAStarPipeline:
         check(self.lib.pp_pipeline_poll(self.h, int(max_results), ptr(tickets), ptr(res), 1, C.byref(k)))
         return tickets[:k.value], res[:k.value]
 
+    def backlog(self):
+        """(ready, searching): queries whose field is built and waiting for a row / claimed by a row, as of the last poll"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(self.lib.pp_pipeline_backlog(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def timings(self):
         """kernel launch durations since the last call (pp_pipeline_timings), as a dict"""
         a, d, f = C.c_double(), C.c_double(), C.c_double()
