@@ -364,8 +364,8 @@ int pp_pipeline_capacity(pp_pipeline* pipeline);
 int pp_pipeline_search_rows(pp_pipeline* pipeline);
 int pp_pipeline_in_flight(pp_pipeline* pipeline);  /* submitted and not yet polled */
 int pp_pipeline_free_slots(pp_pipeline* pipeline);
-/* Where the queries in flight are (as of the last poll, asynchronously): ready = fields built, waiting for a search row; searching = claimed
- * by a row, not yet announced.  A ready queue near 0 = the wavefront stage is the bottleneck, a long one = the search grid is. */
+/* Where the queries in flight are, as the row that announced the latest polled result saw the queue's counters (they ride in every
+ * completion record): ready = fields built, waiting for a search row; searching = claimed by a row, not yet polled.  A ready queue near 0 = the wavefront stage is the bottleneck, a long one = the search grid is. */
 int pp_pipeline_backlog(pp_pipeline* pipeline, int64_t* ready, int64_t* searching);
 /* Kernel launch durations since the last call (HIP events on the launching streams), then reset: total milliseconds / launches / goals of
  * the wavefront kernel; total milliseconds / launches of the search grid and its longest launch (a launch that tops up a full grid lasts

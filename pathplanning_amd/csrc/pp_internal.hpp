@@ -86,6 +86,8 @@ struct WavefrontPublish {
 	unsigned long long* readyTail = nullptr; // entries appended so far (absolute)
 	unsigned long long* ready = nullptr;     // ring of (position + 1) << 32 | slot
 	unsigned long long readyMask = 0;        // ring size - 1 (a power of two)
+	int* goalCounter = nullptr;              // the launch's goal counter when it is not the word behind the error flag (the pipeline keeps
+	                                         // the error flag in pinned host memory, where no device atomic should go)
 };
 hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
 	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev = nullptr, bool tiledOut = false,

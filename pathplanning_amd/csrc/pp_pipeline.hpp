@@ -66,8 +66,8 @@ struct pp_pipeline {
 	int32_t* slotStage = nullptr;             // staging of the slot lists (same ring positions as slotLists)
 	unsigned long long* submittedStage = nullptr; // ring of submission counts on their way to ctl->nSubmitted
 	int submittedStagePos = 0;
-	int32_t* errStage = nullptr; // copies of the wavefront error flags, refreshed by every poll
-	PipeCtl* ctlStage = nullptr; // copy of the device control block, refreshed by every poll (pp_pipeline_backlog reads the last one)
+	int32_t* errFlags = nullptr; // [streams] the wavefront kernels' error flags, in pinned host memory: written by the device, read by poll
+	unsigned long long lastTail = 0, lastHead = 0; // the ready queue's counters as the latest completion record saw them
 	// streams
 	hipStream_t wfStream[kPipeWavefrontStreams] = {}, searchStream[kPipeSearchStreams] = {}, ctlStream = nullptr;
 	hipEvent_t evIngest = nullptr, evCtl = nullptr;
@@ -122,7 +122,7 @@ void free_pipeline(pp_pipeline* P)
 	for (void* q : dev)
 		if (q)
 			(void)hipFree(q);
-	void* host[] = { P->done, P->slotStage, P->submittedStage, P->errStage, P->ctlStage };
+	void* host[] = { P->done, P->slotStage, P->submittedStage, P->errFlags };
 	for (void* q : host)
 		if (q)
 			(void)hipHostFree(q);
@@ -280,9 +280,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	if (e == hipSuccess)
 		e = hipHostMalloc((void**)&P->submittedStage, 64 * 8, hipHostMallocDefault);
 	if (e == hipSuccess)
-		e = hipHostMalloc((void**)&P->errStage, 64, hipHostMallocDefault);
-	if (e == hipSuccess)
-		e = hipHostMalloc((void**)&P->ctlStage, sizeof(PipeCtl), hipHostMallocDefault);
+		e = hipHostMalloc((void**)&P->errFlags, 64, hipHostMallocDefault);
 	if (e == hipSuccess)
 		e = hipMemset(P->ctl, 0, sizeof(PipeCtl));
 	if (e == hipSuccess)
@@ -296,8 +294,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		return pph::hip_fail(e, "pipeline allocation");
 	}
 	std::memset(P->done, 0, ring * sizeof(PipeDone));
-	std::memset(P->errStage, 0, 64);
-	std::memset(P->ctlStage, 0, sizeof(PipeCtl));
+	std::memset(P->errFlags, 0, 64);
 	P->freeSlots.resize((size_t)capacity);
 	for (int i = 0; i < capacity; i++)
 		P->freeSlots[(size_t)i] = capacity - 1 - i; // slot 0 is handed out first
@@ -384,6 +381,7 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	// ---- inputs into their slots: on the control stream (never busy for long), so the caller's arrays are free when this returns
 	hipStream_t const w = P->wfStream[P->nextWf];
 	int32_t* const wctl = P->wfCtl[P->nextWf];
+	int32_t* const werr = P->errFlags + P->nextWf; // (pinned host memory: the kernel's plain store reaches it, poll reads it)
 	void* const wws = P->wfWorkspace[P->nextWf];
 	P->nextWf = (P->nextWf + 1) % P->nWf;
 	PP_HIP_TRY(hipMemcpyAsync(listDev, stage, (size_t)k * 4, hipMemcpyHostToDevice, P->ctlStream));
@@ -393,15 +391,16 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	PP_HIP_TRY(hipStreamSynchronize(P->ctlStream));
 	// ---- ObstaclesHeuristic::Update for every goal (hybrid_a_star.cpp:249); each finished slot is appended to the ready ring
 	PP_HIP_TRY(hipStreamWaitEvent(w, P->evIngest, 0));
-	PP_HIP_TRY(hipMemsetAsync(wctl + 1, 0, 4, w)); // this launch's goal counter (the error flag at wctl[0] stays)
+	PP_HIP_TRY(hipMemsetAsync(wctl + 1, 0, 4, w)); // this launch's goal counter
 	pl->args.m = pl->map->view();
 	pph::WavefrontPublish pub;
 	pub.slotList = listDev;
 	pub.readyTail = &P->ctl->readyTail;
 	pub.ready = P->ready;
 	pub.readyMask = P->readyMask;
+	pub.goalCounter = wctl + 1;
 	const pp_pipeline::Timed tm = timed_take(P, w, 0, k);
-	PP_HIP_TRY(pph::launch_wavefront(w, pl->args.m, k, nullptr, pl->costFields, wws, pl->wfBytesPerSlot, P->wfBlocks, wctl, nullptr, /*tiledOut=*/true, /*goalPoses=*/pl->dGoals,
+	PP_HIP_TRY(pph::launch_wavefront(w, pl->args.m, k, nullptr, pl->costFields, wws, pl->wfBytesPerSlot, P->wfBlocks, werr, nullptr, /*tiledOut=*/true, /*goalPoses=*/pl->dGoals,
 		/*countersZeroed=*/true, nullptr, nullptr, nullptr, nullptr, pub));
 	timed_done(P, w, tm);
 	P->nSubmitted += (unsigned long long)k;
@@ -460,6 +459,8 @@ int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out,
 			return PP_ERR_HIP;
 		}
 		pl->hostResults[(size_t)slot] = rec->r;
+		P->lastTail = rec->readyTail;
+		P->lastHead = rec->readyHead;
 		tickets_out[n] = P->ticketOfSlot[(size_t)slot];
 		results_out[n] = rec->r.r;
 		if (release) {
@@ -474,20 +475,19 @@ int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out,
 	}
 	*n_out = n;
 	timed_harvest(P);
-	// the wavefront kernels' error flags come over asynchronously; what an earlier poll asked for is looked at now
-	if (P->errStage[0] || P->errStage[1] || P->errStage[2] || P->errStage[3]) {
+	// the wavefront kernels raise their error flags in pinned host memory: no copy, no HIP call on this path
+	if (__atomic_load_n(&P->errFlags[0], __ATOMIC_RELAXED) || __atomic_load_n(&P->errFlags[1], __ATOMIC_RELAXED) || __atomic_load_n(&P->errFlags[2], __ATOMIC_RELAXED) ||
+		__atomic_load_n(&P->errFlags[3], __ATOMIC_RELAXED)) {
 		set_error("obstacle-heuristic open list exceeded its workspace");
 		return PP_ERR_CAPACITY;
 	}
 	if (P->nSubmitted > P->doneHead) {
-		PP_HIP_TRY(hipSetDevice(pl->map->ctx->device));
-		for (int i = 0; i < P->nWf; i++)
-			PP_HIP_TRY(hipMemcpyAsync(P->errStage + i, P->wfCtl[i], 4, hipMemcpyDeviceToHost, P->ctlStream));
-		PP_HIP_TRY(hipMemcpyAsync(P->ctlStage, P->ctl, sizeof(PipeCtl), hipMemcpyDeviceToHost, P->ctlStream));
 		// waves that left on their own (no work for idleTicks) are replaced while queries are outstanding
 		const auto now = std::chrono::steady_clock::now();
-		if (std::chrono::duration_cast<std::chrono::milliseconds>(now - P->lastLaunch).count() >= 100) // (twice the waves' own idle time-out)
+		if (std::chrono::duration_cast<std::chrono::milliseconds>(now - P->lastLaunch).count() >= 100) { // (twice the waves' own idle time-out)
+			PP_HIP_TRY(hipSetDevice(pl->map->ctx->device));
 			return pipe_launch_search(P);
+		}
 	}
 	return PP_OK;
 }
@@ -539,8 +539,8 @@ int pp_pipeline_timings(pp_pipeline* P, double* wavefront_ms_total, int64_t* wav
 	return PP_OK;
 }
 
-/// Where the queries in flight are, as of the copy of the control block an earlier poll asked for (asynchronous: a few hundred
-/// microseconds old): ready = fields built and waiting for a search row; searching = claimed by a row and not yet announced;
+/// Where the queries in flight are, as the row that announced the latest polled result saw the queue's counters (every completion
+/// record carries them: no copy, no HIP call): ready = fields built and waiting for a search row; searching = claimed by a row and not yet polled;
 /// the rest of pp_pipeline_in_flight() is still with the wavefront kernel (or completed and not yet polled).
 /// ready near 0 with rows to spare = the wavefront stage is the bottleneck; a long ready queue = the search grid is.
 int pp_pipeline_backlog(pp_pipeline* P, int64_t* ready, int64_t* searching)
@@ -549,11 +549,10 @@ int pp_pipeline_backlog(pp_pipeline* P, int64_t* ready, int64_t* searching)
 		set_error("null pipeline");
 		return PP_ERR_INVALID;
 	}
-	const PipeCtl c = *P->ctlStage;
 	if (ready)
-		*ready = (int64_t)(c.readyTail - c.readyHead);
+		*ready = (int64_t)(P->lastTail - P->lastHead);
 	if (searching)
-		*searching = (int64_t)(c.readyHead - c.doneTail);
+		*searching = (int64_t)(P->lastHead - P->doneHead);
 	return PP_OK;
 }
 

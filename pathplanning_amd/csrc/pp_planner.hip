@@ -1148,6 +1148,7 @@ struct PipeCtl {
 struct PipeDone {
 	unsigned long long stamp;
 	DevResult r;
+	unsigned long long readyTail, readyHead; // the queue counters as the announcing row saw them (pp_pipeline_backlog)
 };
 struct PipeView {
 	PipeCtl* ctl = nullptr; // nullptr: the kernel works on a batch (no pipeline)

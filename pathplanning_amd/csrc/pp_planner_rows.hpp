@@ -337,6 +337,8 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				const unsigned long long d = __hip_atomic_fetch_add(&pipe.ctl->doneTail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				PipeDone* const rec = pipe.done + (d & pipe.doneMask);
 				rec->r = r;
+				rec->readyTail = __hip_atomic_load(&pipe.ctl->readyTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				rec->readyHead = __hip_atomic_load(&pipe.ctl->readyHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				__hip_atomic_store(&rec->stamp, ((d + 1ull) << 32) | (unsigned long long)(uint32_t)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -1308,16 +1308,16 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 	int grid = nGoals < nSlots ? nGoals : nSlots;
 	// errorFlagDev[0] = overflow flag, errorFlagDev[1] = next-goal counter
 	if (!countersZeroed) {
-		hipError_t e = hipMemsetAsync(errorFlagDev + 1, 0, sizeof(int), s);
+		hipError_t e = hipMemsetAsync(pub.goalCounter ? (void*)pub.goalCounter : (void*)(errorFlagDev + 1), 0, sizeof(int), s);
 		if (e != hipSuccess)
 			return e;
 	}
 	if (profDev)
 		hipLaunchKernelGGL(k_wavefront<true>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev, pub);
+			profDev, pub.goalCounter ? pub.goalCounter : (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev, pub);
 	else
 		hipLaunchKernelGGL(k_wavefront<false>, dim3(grid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
-			profDev, (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev, pub);
+			profDev, pub.goalCounter ? pub.goalCounter : (int*)(errorFlagDev + 1), tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, orderOutDev, doneCounterDev, orderKeysDev, pub);
 	return hipGetLastError();
 }
 
