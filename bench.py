@@ -213,6 +213,7 @@ def main():
     d_starts_rep, d_goals_rep, d_seeds_rep = (d_starts.repeat(rep, 1), d_goals.repeat(rep, 1), d_seeds.repeat(rep)) if rep > 1 else (d_starts, d_goals, d_seeds)
 
     backlog = []  # (ready, searching) samples of the last run_steps_pipeline
+    tail_marks, tail_info = [], {}
 
     def run_steps_pipeline(k):
         """k steps = k x B queries through the library's pipeline: submitted as slots are free, polled in completion order.  Returns the
@@ -223,6 +224,9 @@ def main():
         sums = dict(success=0, expansions=0, rs_attempts=0, rng_draws=0, state_checks=0, path_checks=0)
         base = None
         backlog.clear()
+        tail_marks.clear()
+        t_run0 = time.perf_counter()
+        last_submit = [0.0]
         while done < total:
             if submitted < total:
                 free = pipe.free_slots()
@@ -233,6 +237,7 @@ def main():
                     if base is None:
                         base = first
                     submitted += kk
+                    last_submit[0] = time.perf_counter() - t_run0
             tickets, res = pipe.poll_array(8192)
             backlog.append(pipe.backlog())
             if len(tickets):
@@ -246,10 +251,15 @@ def main():
                 sums["state_checks"] += int(res["n_state_checks"].sum())
                 sums["path_checks"] += int(res["n_path_checks"].sum())
                 done += len(tickets)
+                tail_marks.append((time.perf_counter(), done))
                 if world > 1:
                     step_records.append(np.column_stack([res["status"].astype(np.float64), res["cost"], res["n_expanded"].astype(np.float64), res["n_path"].astype(np.float64)]))
             else:
                 time.sleep(0.0002)
+        # how the run ends: when the last submission went in, and when 90 / 99 / 99.9 / 100 % of the results had arrived
+        tm = np.array([(t - t_run0, d) for t, d in tail_marks])
+        tail_info.clear()
+        tail_info.update(last_submission_s=last_submit[0], **{"done_%s_s" % str(f).replace(".", "_"): float(tm[np.searchsorted(tm[:, 1], f * total / 100.0), 0]) for f in (50, 90, 99, 99.9, 100)})
         return last, sums
 
     def sync_all():
@@ -456,7 +466,7 @@ def main():
             "roofline_per_kernel": roofs,
             "map_build": map_info,
             **({"pipeline_kernel_timings": pipe_kernel, "run_totals": run_sums,
-                "pipeline_backlog": dict(samples=len(backlog), ready_mean=float(np.mean([b[0] for b in backlog])), ready_p10=float(np.percentile([b[0] for b in backlog], 10)),
+                "run_profile": dict(tail_info), "pipeline_backlog": dict(samples=len(backlog), ready_mean=float(np.mean([b[0] for b in backlog])), ready_p10=float(np.percentile([b[0] for b in backlog], 10)),
                                          ready_max=int(max(b[0] for b in backlog)), searching_mean=float(np.mean([b[1] for b in backlog])), rows=pipe.search_rows)} if pipeline_mode else {}),
             "cpu_baseline": cpu,
         }
