@@ -37,6 +37,11 @@ __device__ unsigned long long g_rowsStats[24];
 #endif
 
 // --------------------------------------------------------------------------------------------------- kernel --
+#ifndef PP_PIPE_POLL_EVERY
+#define PP_PIPE_POLL_EVERY 8
+#endif
+constexpr int kPollEvery = PP_PIPE_POLL_EVERY; // pipeline: an idle row that found the ring empty looks again every kPollEvery-th pass of its wave
+
 template <bool kPiped>
 __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search_rows(SearchArgs A, int nQueries, const double* __restrict__ starts,
 	const double* __restrict__ goals, const uint64_t* __restrict__ seeds, const float* __restrict__ costFields, Node* __restrict__ nodesBase,
@@ -84,6 +89,8 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the previous owner's last stores to the rows' buffers
 	}
 	int idleIters = 0; // (wave-uniform) consecutive loop passes with every row idle
+	unsigned passCount = 0; // (wave-uniform, pipeline) loop passes: a row that found the ring empty looks again every kPollEvery-th pass only
+	bool pollNow = true;    // (pipeline) this row looks at the ring on the next pass whatever the pass count (it has just finished a query, or lost a race)
 	size_t slot = (size_t)waveIdx * kRowsPerWave + (size_t)(lane >> 4);
 	Node* nodes = nodesBase + slot * A.maxNodes;
 	HeapEntry* heap = heapBase + slot * A.maxNodes;
@@ -345,6 +352,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			}
 		}
 		act = false;
+		pollNow = true;
 	};
 
 #if PP_ROWS_STATS
@@ -375,17 +383,24 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			if (piped) {
 				// the ring's head entry, if it carries the stamp of its position (the wavefront kernel stores an entry after reserving its
 				// place, so the head may be reserved but not yet written: then there is nothing to take right now)
-				int got = -1;
-				if (rl == 0) {
-					// (one attempt per loop pass: a row that loses the race for the head entry tries again after its neighbours' next expansion)
+				// An idle row's look at the ring is two dependent reads at the L2 (about 2 us) that the BUSY rows of the wave wait for: with the
+				// ring empty most of the time (the wavefront kernel paces the pipeline) every pass of a wave with an idle row paid them.  So a
+				// row that found the ring empty looks again on every kPollEvery-th pass of its wave (all idle rows of a wave on the same pass); a
+				// row that has just finished, or lost the race for an entry that was there, looks on the next pass.  (Measured neutral on the
+				// bench's plans/s -- 15.4-15.9 k over 20 steps either way: the busy rows' passes are bound elsewhere -- and kept for the eighth
+				// of the atomic traffic on the control block.)
+				int got = -1; // -1: nothing there (or not looked), -2: an entry was there and another row took it
+				const bool look = pollNow || (passCount % (unsigned)kPollEvery) == 0u;
+				if (rl == 0 && look) {
 					unsigned long long h = __hip_atomic_load(&pipe.ctl->readyHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					const unsigned long long e = __hip_atomic_load(pipe.ready + (h & pipe.readyMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if ((uint32_t)(e >> 32) == (uint32_t)(h + 1ull) &&
-						__hip_atomic_compare_exchange_strong(&pipe.ctl->readyHead, &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-						got = (int)(uint32_t)e;
+					if ((uint32_t)(e >> 32) == (uint32_t)(h + 1ull))
+						got = __hip_atomic_compare_exchange_strong(&pipe.ctl->readyHead, &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+							? (int)(uint32_t)e : -2;
 				}
 				q = (int)row_read((uint32_t)got, lane, 0);
 				none = q < 0;
+				pollNow = q == -2; // an entry was there and another row took it
 				if (!none) {
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the field, and the slot's start / goal / seed
 				}
@@ -547,6 +562,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			}
 		}
 		const unsigned long long actMask = __ballot(act);
+		passCount++;
 #if PP_ROWS_STATS
 		if (lane == 0 && actMask)
 			statIter[__popcll(actMask) / kRowLanes]++;
