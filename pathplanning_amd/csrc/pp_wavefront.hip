@@ -1306,6 +1306,11 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 	uint32_t fcap, gcap;
 	wf_caps(m.rows, m.cols, fcap, gcap);
 	int grid = nGoals < nSlots ? nGoals : nSlots;
+	if (const char* e = getenv("PP_WF_GRID")) { // diagnostic: fewer resident workgroups (is a goal's latency independent of its neighbours on the CU?)
+		const int g = atoi(e);
+		if (g > 0 && g < grid)
+			grid = g;
+	}
 	// errorFlagDev[0] = overflow flag, errorFlagDev[1] = next-goal counter
 	if (!countersZeroed) {
 		hipError_t e = hipMemsetAsync(pub.goalCounter ? (void*)pub.goalCounter : (void*)(errorFlagDev + 1), 0, sizeof(int), s);
