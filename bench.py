@@ -225,6 +225,7 @@ def main():
         base = None
         backlog.clear()
         tail_marks.clear()
+        late = []
         t_run0 = time.perf_counter()
         last_submit = [0.0]
         while done < total:
@@ -252,6 +253,8 @@ def main():
                 sums["path_checks"] += int(res["n_path_checks"].sum())
                 done += len(tickets)
                 tail_marks.append((time.perf_counter(), done))
+                if done > 0.98 * total:  # what the run ends with: arrival time, submission index, expansions, status of the late results
+                    late.extend((time.perf_counter() - t_run0, int(i), int(r["n_expanded"]), int(r["status"])) for i, r in zip(idx, res))
                 if world > 1:
                     step_records.append(np.column_stack([res["status"].astype(np.float64), res["cost"], res["n_expanded"].astype(np.float64), res["n_path"].astype(np.float64)]))
             else:
@@ -260,7 +263,17 @@ def main():
         tm = np.array([(t - t_run0, d) for t, d in tail_marks])
         tail_info.clear()
         tail_info.update(last_submission_s=last_submit[0], **{"done_%s_s" % str(f).replace(".", "_"): float(tm[np.searchsorted(tm[:, 1], f * total / 100.0), 0]) for f in (50, 90, 99, 99.9, 100)})
+        # the last results to arrive: [arrival s, position of the query in the run as a fraction, expansions, status, min clearance of start / goal in m]
+        qi = np.array([x[1] for x in late[-12:]], dtype=np.int64) % B
+        clr = np.minimum(query_clearance(starts[qi]), query_clearance(goals[qi])) if len(qi) else []
+        tail_info["last_results"] = [[round(t, 3), round(i / total, 3), ne, st, round(float(c), 2)] for (t, i, ne, st), c in zip(late[-12:], clr)]
         return last, sums
+
+    def query_clearance(p):
+        res_m = float(ms.resolution)
+        r = np.clip(((p[:, 0] - ms.grid_origin[0]) / res_m).astype(np.int64), 0, ms.rows - 1)
+        c = np.clip(((p[:, 1] - ms.grid_origin[1]) / res_m).astype(np.int64), 0, ms.cols - 1)
+        return np.sqrt(m["d2"][r, c].astype(np.float64)) * res_m
 
     def sync_all():
         if world > 1:
@@ -465,7 +478,11 @@ def main():
             "roofline": roof,
             "roofline_per_kernel": roofs,
             "map_build": map_info,
+            # every step replays the same B queries: the run's totals must be `steps` times the last step's (a field built for the wrong goal, or a
+            # result delivered twice, would show here)
             **({"pipeline_kernel_timings": pipe_kernel, "run_totals": run_sums,
+                "replay_consistent": bool(run_sums["expansions"] == args.steps * n_expanded and run_sums["success"] == args.steps * n_success and
+                                          run_sums["rng_draws"] == args.steps * sum(r.n_rng_draws for r in res) and run_sums["state_checks"] == args.steps * state_checks),
                 "run_profile": dict(tail_info), "pipeline_backlog": dict(samples=len(backlog), ready_mean=float(np.mean([b[0] for b in backlog])), ready_p10=float(np.percentile([b[0] for b in backlog], 10)),
                                          ready_max=int(max(b[0] for b in backlog)), searching_mean=float(np.mean([b[1] for b in backlog])), rows=pipe.search_rows)} if pipeline_mode else {}),
             "cpu_baseline": cpu,

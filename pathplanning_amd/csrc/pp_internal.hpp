@@ -81,6 +81,9 @@ hipError_t warm_up_wavefront(hipStream_t s, const ppd::MapView& m, int32_t* ctlD
 /// reads); otherwise [nGoals][rows*cols] row-major (the public a8 entry points).
 /// Pipeline use of the wavefront kernel (pp_pipeline.hpp): entry i of a launch works on field slot slotList[i] (goal pose and output
 /// field are indexed by the slot), and every finished slot is appended to the ready ring the search grid consumes.
+constexpr int kSlotBits = 20;                 // pipeline list / ring entries: field slot in the low bits, the slot's generation above
+constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1u;
+constexpr uint32_t kGenMask = (1u << (31 - kSlotBits)) - 1u; // (entries are non-negative int32)
 struct WavefrontPublish {
 	const int32_t* slotList = nullptr;
 	unsigned long long* readyTail = nullptr; // entries appended so far (absolute)
@@ -88,6 +91,14 @@ struct WavefrontPublish {
 	unsigned long long readyMask = 0;        // ring size - 1 (a power of two)
 	int* goalCounter = nullptr;              // the launch's goal counter when it is not the word behind the error flag (the pipeline keeps
 	                                         // the error flag in pinned host memory, where no device atomic should go)
+	// Goals that should not wait for their launch's turn (pp_pipeline.hpp, "urgent"): a ring of stamped slot numbers shared by ALL launches of a
+	// pipeline -- a workgroup of any launch in flight serves it before it takes the next goal of its own list -- and one claim word per slot
+	// (generation << 1 -> generation << 1 | 1 by whoever builds the slot's field: a slot sits in its launch's list AND, if urgent, in the ring;
+	// list and ring entries are slot | generation << kSlotBits, see k_wavefront's hand-out).
+	unsigned long long* urgent = nullptr;
+	unsigned long long* urgentHead = nullptr; // entries claimed so far (absolute)
+	unsigned long long urgentMask = 0;
+	int* claimed = nullptr;
 };
 hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
 	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev = nullptr, bool tiledOut = false,

@@ -27,19 +27,47 @@
 
 namespace {
 
-/// start / goal / seed of a submission into their field slots
+/// start / goal / seed of a submission into their field slots.  Queries whose start or goal pose stands closer than `urgentClearance` to an
+/// obstacle or to the edge of the state space are ALSO appended to the urgent ring (WavefrontPublish::urgent): on the bench map such poses are 17 % of the queries and
+/// carry 17 of the 18 queries per 4096 that exhaust the lattice (65 k expansions, ~0.9 s: tools/study_failures.py) -- the queries that decide
+/// when a run ends.  Their fields are built by whatever wavefront launch is running, ahead of the submissions queued before them, so that
+/// their long searches start at once instead of after their launch's turn.  Results do not depend on any of this (order of work only).
 __global__ void __launch_bounds__(256) k_pipe_scatter(int n, const int32_t* __restrict__ slotList, const double* __restrict__ startsIn, const double* __restrict__ goalsIn,
-	const uint64_t* __restrict__ seedsIn, double* __restrict__ starts, double* __restrict__ goals, uint64_t* __restrict__ seeds)
+	const uint64_t* __restrict__ seedsIn, double* __restrict__ starts, double* __restrict__ goals, uint64_t* __restrict__ seeds, MapView m, float urgentClearance, PipeCtl* ctl,
+	unsigned long long* __restrict__ urgent, unsigned long long urgentMask, int* __restrict__ claimed)
 {
 	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
 	if (i >= n)
 		return;
-	const size_t s = (size_t)slotList[i];
+	const uint32_t entry = (uint32_t)slotList[i]; // slot | generation << kSlotBits
+	const size_t s = (size_t)(entry & pph::kSlotMask);
 	for (int k = 0; k < 3; k++) {
 		starts[3 * s + k] = startsIn[3 * (size_t)i + k];
 		goals[3 * s + k] = goalsIn[3 * (size_t)i + k];
 	}
 	seeds[s] = seedsIn[i];
+	if (!claimed)
+		return;
+	claimed[s] = (int)((entry >> pph::kSlotBits) << 1); // this generation, not yet claimed (see k_wavefront's hand-out)
+	if (!(urgentClearance > 0.0f))
+		return;
+	float clearance = __builtin_huge_valf();
+	for (int k = 0; k < 2; k++) {
+		const double* p = (k ? goalsIn : startsIn) + 3 * (size_t)i;
+		int row, col;
+		world_to_cell(m, p[0], p[1], row, col);
+		if (inside_map(m, row, col))
+			clearance = fminf(clearance, m.dist[(size_t)row * m.cols + col]);
+		// the edge of the state space confines the car like a wall (the distance grid knows obstacles only)
+		clearance = fminf(clearance, (float)fmin(fmin(p[0] - m.lbx, m.ubx - p[0]), fmin(p[1] - m.lby, m.uby - p[1])));
+	}
+	if (clearance < urgentClearance) {
+		// the slot's inputs and claim word reach memory before the entry can be seen (the consumer may belong to a launch that is already running)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const unsigned long long t = __hip_atomic_fetch_add(&ctl->urgentTail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(urgent + (t & urgentMask), ((t + 1ull) << 32) | (unsigned long long)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 }
 
 constexpr int kPipeSearchStreams = 4;
@@ -56,6 +84,9 @@ struct pp_pipeline {
 	unsigned long long* ready = nullptr;
 	unsigned long long readyMask = 0;
 	int* waveAlive = nullptr;
+	unsigned long long* urgent = nullptr; // ring of urgent slots (k_pipe_scatter -> any running wavefront launch), same size as the ready ring
+	int* claimed = nullptr;               // [capacity] 0 -> 1 by the workgroup that builds the slot's field
+	float urgentClearance = 2.0f;         // [m] queries with a start or goal pose closer than this to an obstacle go through the urgent ring; 0 = none
 	int32_t* slotLists = nullptr; // ring of slot lists, one segment per wavefront launch in flight
 	size_t slotListCap = 0, slotListPos = 0;
 	void* wfWorkspace[kPipeWavefrontStreams] = {};
@@ -76,6 +107,7 @@ struct pp_pipeline {
 	std::vector<int32_t> freeSlots;
 	std::vector<uint64_t> ticketOfSlot;
 	std::vector<uint8_t> slotState; // 0 free, 1 in flight, 2 completed and held for the caller
+	std::vector<uint32_t> slotGen;  // times the slot has been filled (mod kGenMask + 1, never 0): tags its list / ring entries and its claim word
 	std::unordered_map<uint64_t, int32_t> slotOfTicket;
 	unsigned long long nSubmitted = 0, doneHead = 0, nTickets = 0;
 	std::chrono::steady_clock::time_point lastLaunch {};
@@ -118,7 +150,7 @@ void free_pipeline(pp_pipeline* P)
 			if (t.b)
 				(void)hipEventDestroy(t.b);
 		}
-	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfWorkspace[2], P->wfWorkspace[3], P->wfCtl[0], P->wfCtl[1], P->wfCtl[2], P->wfCtl[3] };
+	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->urgent, P->claimed, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfWorkspace[2], P->wfWorkspace[3], P->wfCtl[0], P->wfCtl[1], P->wfCtl[2], P->wfCtl[3] };
 	for (void* q : dev)
 		if (q)
 			(void)hipFree(q);
@@ -224,8 +256,8 @@ extern "C" {
 
 int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capacity, int32_t max_nodes_per_query, int32_t search_rows, int32_t log_expansions, pp_pipeline** out)
 {
-	if (!map || !params || !out || capacity < 4 || max_nodes_per_query < 16 || search_rows < 0) {
-		set_error("invalid arguments (capacity >= 4)");
+	if (!map || !params || !out || capacity < 4 || capacity > (int32_t)pph::kSlotMask || max_nodes_per_query < 16 || search_rows < 0) {
+		set_error("invalid arguments (4 <= capacity < 2^20)");
 		return PP_ERR_INVALID;
 	}
 	PP_HIP_TRY(hipSetDevice(map->ctx->device));
@@ -251,6 +283,15 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		e = hipMalloc((void**)&P->waveAlive, (size_t)P->waves * 4);
 	if (e == hipSuccess)
 		e = hipMalloc((void**)&P->slotLists, P->slotListCap * 4);
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&P->urgent, ring * 8);
+	if (e == hipSuccess)
+		e = hipMalloc((void**)&P->claimed, (size_t)capacity * 4);
+	if (const char* v = getenv("PP_PIPE_URGENT_CLEARANCE")) { // [m]; 0 switches the urgent ring off
+		const double x = strtod(v, nullptr);
+		if (x >= 0.0 && x < 1.0e6)
+			P->urgentClearance = (float)x;
+	}
 	if (const char* v = getenv("PP_PIPE_WF_STREAMS")) {
 		const long x = strtol(v, nullptr, 10);
 		if (x >= 1 && x <= kPipeWavefrontStreams)
@@ -288,6 +329,10 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	if (e == hipSuccess)
 		e = hipMemset(P->waveAlive, 0, (size_t)P->waves * 4);
 	if (e == hipSuccess)
+		e = hipMemset(P->urgent, 0, ring * 8);
+	if (e == hipSuccess)
+		e = hipMemset(P->claimed, 0, (size_t)capacity * 4);
+	if (e == hipSuccess)
 		e = hipDeviceSynchronize();
 	if (e != hipSuccess) {
 		free_pipeline(P);
@@ -300,6 +345,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		P->freeSlots[(size_t)i] = capacity - 1 - i; // slot 0 is handed out first
 	P->ticketOfSlot.assign((size_t)capacity, 0);
 	P->slotState.assign((size_t)capacity, 0);
+	P->slotGen.assign((size_t)capacity, 0u);
 	pl->hostResults.resize((size_t)capacity);
 	pl->lastBatch = capacity;
 	{
@@ -370,7 +416,9 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	for (int i = 0; i < k; i++) {
 		const int32_t s = P->freeSlots.back();
 		P->freeSlots.pop_back();
-		stage[i] = s;
+		uint32_t& gen = P->slotGen[(size_t)s];
+		gen = gen >= pph::kGenMask ? 1u : gen + 1u;
+		stage[i] = (int32_t)((uint32_t)s | (gen << pph::kSlotBits));
 		P->slotState[(size_t)s] = 1;
 		const uint64_t ticket = P->nTickets++;
 		P->ticketOfSlot[(size_t)s] = ticket;
@@ -385,7 +433,9 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	void* const wws = P->wfWorkspace[P->nextWf];
 	P->nextWf = (P->nextWf + 1) % P->nWf;
 	PP_HIP_TRY(hipMemcpyAsync(listDev, stage, (size_t)k * 4, hipMemcpyHostToDevice, P->ctlStream));
-	hipLaunchKernelGGL(k_pipe_scatter, dim3((k + 255) / 256), dim3(256), 0, P->ctlStream, k, listDev, starts_dev, goals_dev, seeds_dev, pl->dStarts, pl->dGoals, pl->dSeeds);
+	pl->args.m = pl->map->view();
+	hipLaunchKernelGGL(k_pipe_scatter, dim3((k + 255) / 256), dim3(256), 0, P->ctlStream, k, listDev, starts_dev, goals_dev, seeds_dev, pl->dStarts, pl->dGoals, pl->dSeeds, pl->args.m,
+		P->urgentClearance, P->ctl, P->urgent, P->readyMask, P->claimed);
 	PP_HIP_TRY(hipGetLastError());
 	PP_HIP_TRY(hipEventRecord(P->evIngest, P->ctlStream));
 	PP_HIP_TRY(hipStreamSynchronize(P->ctlStream));
@@ -399,6 +449,12 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	pub.ready = P->ready;
 	pub.readyMask = P->readyMask;
 	pub.goalCounter = wctl + 1;
+	pub.claimed = P->claimed;
+	if (P->urgentClearance > 0.0f) {
+		pub.urgent = P->urgent;
+		pub.urgentHead = &P->ctl->urgentHead;
+		pub.urgentMask = P->readyMask;
+	}
 	const pp_pipeline::Timed tm = timed_take(P, w, 0, k);
 	PP_HIP_TRY(pph::launch_wavefront(w, pl->args.m, k, nullptr, pl->costFields, wws, pl->wfBytesPerSlot, P->wfBlocks, werr, nullptr, /*tiledOut=*/true, /*goalPoses=*/pl->dGoals,
 		/*countersZeroed=*/true, nullptr, nullptr, nullptr, nullptr, pub));

@@ -1142,6 +1142,8 @@ struct PipeCtl {
 	unsigned long long nSubmitted; // queries handed to the wavefront kernel so far (written by the host, in stream order before a top-up launch)
 	int stop;                      // host: leave as soon as the rows are idle
 	int pad[3];
+	unsigned long long urgentTail; // urgent ring (WavefrontPublish::urgent): entries appended by k_pipe_scatter
+	unsigned long long urgentHead; // entries claimed by wavefront workgroups
 };
 /// completion record in PINNED HOST memory: the row writes the result, then the stamp ((position + 1) << 32 | slot); the host consumes
 /// records in position order as their stamps appear

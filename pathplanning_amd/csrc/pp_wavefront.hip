@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 	__shared__ uint64_t s_wtot[WF_W];
 	__shared__ uint32_t s_wsum[WF_W];
 	__shared__ uint32_t s_minNext[2], s_packFail, s_cand;
-	__shared__ int s_goal;
+	__shared__ int s_goal, s_start;
 	uint32_t* const hcell = reinterpret_cast<uint32_t*>(skey);          // [WF_HCAP] padded cell index + 1, 0 = empty
 	uint32_t* const hkey = reinterpret_cast<uint32_t*>(skey) + WF_HCAP; // [WF_HCAP] min (i*8+j)
 
@@ -598,15 +598,73 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				const unsigned long long t = __hip_atomic_fetch_add(pub.readyTail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__hip_atomic_store(pub.ready + (t & pub.readyMask), ((t + 1ull) << 32) | (unsigned long long)(uint32_t)pendingSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
-			s_goal = atomicAdd(goalCounter, 1);
+			// ---- the next goal: an entry of the pipeline's urgent ring if there is one (whatever launch it came with), else the next of this
+			// launch's own list.  Pipeline entries are (slot | generation << 20) and every slot has a claim word, `generation << 1` when the slot
+			// was filled: whoever moves it to `generation << 1 | 1` builds the field.  A slot sits in its launch's list AND, if urgent, in the
+			// ring, so it is built once; and an entry that has outlived its query -- an urgent slot may be built by an older launch, searched,
+			// polled and refilled before its own launch reaches its list entry -- carries a generation that no longer matches and is skipped
+			// (without the generation that stale entry could claim the refilled slot while its new poses are still on their way to memory).
+			int next = -1;
+			if (pub.urgent) {
+				for (;;) {
+					unsigned long long h = __hip_atomic_load(pub.urgentHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const unsigned long long e = __hip_atomic_load(pub.urgent + (h & pub.urgentMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((uint32_t)(e >> 32) != (uint32_t)(h + 1ull))
+						break; // nothing there (or reserved and not yet written: its own launch will come to it)
+					if (!__hip_atomic_compare_exchange_strong(pub.urgentHead, &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+						continue; // another workgroup took it: look again
+					const int slot = (int)((uint32_t)e & pph::kSlotMask);
+					int expect = (int)(((uint32_t)e >> pph::kSlotBits) << 1);
+					if (__hip_atomic_compare_exchange_strong(pub.claimed + slot, &expect, expect | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+						next = slot;
+						break;
+					}
+				}
+			}
+			while (next < 0) {
+				const int gi = atomicAdd(goalCounter, 1);
+				if (gi >= nGoals)
+					break;
+				if (!pub.slotList) {
+					next = gi;
+				} else {
+					const uint32_t e = (uint32_t)pub.slotList[gi];
+					const int slot = (int)(e & pph::kSlotMask);
+					int expect = (int)((e >> pph::kSlotBits) << 1);
+					if (!pub.claimed || __hip_atomic_compare_exchange_strong(pub.claimed + slot, &expect, expect | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+						next = slot;
+				}
+			}
+			s_goal = next;
+			// the goal's cell.  In the pipeline the pose may have been written while this launch was running (urgent ring): it is read with
+			// agent-scope loads, which do not look at this XCD's possibly stale copy of the line -- cheaper than an acquire fence per goal,
+			// which would drop the XCD's whole L2 contents under the search rows that share it.
+			if (next >= 0) {
+				int32_t st;
+				if (goalPoses) { // (x, y, theta) triples: WorldPositionToGridCell(bounded), heuristics.cpp:115
+					double px, py;
+					if (pub.claimed) {
+						px = __hip_atomic_load(goalPoses + 3 * (size_t)next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						py = __hip_atomic_load(goalPoses + 3 * (size_t)next + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					} else {
+						px = goalPoses[3 * (size_t)next];
+						py = goalPoses[3 * (size_t)next + 1];
+					}
+					int row, col;
+					world_to_cell(m, px, py, row, col);
+					st = inside_map(m, row, col) ? row * m.cols + col : -1;
+				} else {
+					st = goalCells[next];
+				}
+				s_start = st;
+			}
 		}
 		pendingSlot = -1;
 		__syncthreads();
-		const int gi = s_goal;
-		if (gi >= nGoals)
+		// g indexes the goal poses and the output fields: the launch's own numbering, or (pipeline) a field slot
+		const int g = s_goal;
+		if (g < 0)
 			break;
-		// g indexes the goal poses and the output fields: the launch's own numbering, or (pipeline) the field slot of entry gi
-		const int g = pub.slotList ? pub.slotList[gi] : gi;
 		if (pub.ready)
 			pendingSlot = g;
 		if (kProfile) {
@@ -615,14 +673,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			tl = clock64();
 		}
 		float* cost = costOut + (int64_t)g * fieldElems;
-		int32_t start;
-		if (goalPoses) { // (x, y, theta) triples: WorldPositionToGridCell(bounded), heuristics.cpp:115
-			int row, col;
-			world_to_cell(m, goalPoses[3 * g], goalPoses[3 * g + 1], row, col);
-			start = inside_map(m, row, col) ? row * m.cols + col : -1;
-		} else {
-			start = goalCells[g];
-		}
+		const int32_t start = s_start;
 		// ---- every cell starts at +inf / unexplored (heuristics.cpp:108-113).  The field is NOT filled up front: every cell the wavefront
 		// discovers is written exactly once, with its cost, and the cells it never reaches (occupied ones, enclosed pockets) get their +inf
 		// in one pass over the state bytes when the goal is done -- 4 MB of stores per goal less at 1024^2, and the lines of the field

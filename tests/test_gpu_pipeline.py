@@ -76,8 +76,14 @@ def test_pipeline_matches_the_oracle_with_recycled_slots():
     pipe.close()
 
 
-def test_pipeline_equals_the_batch_planner_and_restarts_after_idling():
+@pytest.mark.parametrize("urgent_clearance", [None, "0", "1000"])
+def test_pipeline_equals_the_batch_planner_and_restarts_after_idling(monkeypatch, urgent_clearance):
+    """urgent_clearance: the order-of-work knob of pp_pipeline.hpp (queries with a pose near an obstacle have their fields built ahead of
+    the submissions queued before them, through a ring every running wavefront launch serves): the default (2 m), off, and "every query is
+    urgent" -- each slot then sits in the ring AND in its launch's list and must be built exactly once; results are the batch planner's whatever it is"""
     import pathplanning_amd as pa
+    if urgent_clearance is not None:
+        monkeypatch.setenv("PP_PIPE_URGENT_CLEARANCE", urgent_clearance)
     w, ms, val, ctx = make_pair(512, 12, 1)
     rng = np.random.RandomState(5)
     n = 1500
