@@ -603,7 +603,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			// was filled: whoever moves it to `generation << 1 | 1` builds the field.  A slot sits in its launch's list AND, if urgent, in the
 			// ring, so it is built once; and an entry that has outlived its query -- an urgent slot may be built by an older launch, searched,
 			// polled and refilled before its own launch reaches its list entry -- carries a generation that no longer matches and is skipped
-			// (without the generation that stale entry could claim the refilled slot while its new poses are still on their way to memory).
+			// (without the generation such an entry claims the refilled slot: a goal written AFTER this launch began, reached through the
+			// list path; a version that did so, with the pose read through the caches, built ~1 field in 4096 for the slot's previous goal).
 			int next = -1;
 			if (pub.urgent) {
 				for (;;) {

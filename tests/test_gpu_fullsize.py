@@ -165,3 +165,50 @@ def test_own_table_on_the_benchmark_map():
     assert n_diff == 0, "device-built and glibc-built tables differ on the benchmark map: make the host-built table bench.py's default"
     assert bad_default == [], line
     assert len(bad_pert) <= n // 20, line  # one-ulp entries reorder a tie now and then; they must stay rare
+
+
+def test_full_size_pipeline_replay_equals_the_batch_planner():
+    """bench.py's workload through the streaming pipeline, as bench.py drives it: the 4096 benchmark queries submitted eight times over
+    with three submissions' worth of slots, so that launches queue, urgent slots are built ahead of their launch and every
+    slot is refilled several times.  All 8 x 4096 results must be the batch planner's (status and every counter; cost bit for bit)."""
+    import time
+    import pathplanning_amd as pa
+    from pathplanning_amd import synthetic
+    B, rounds = 4096, 8
+    ctx = pa.Context(0)
+    m = synthetic.make_map(1024, 24, seed=1)
+    ms, val = synthetic.upload(ctx, m)
+    reach = synthetic.reachable_mask(val, m)
+    starts = synthetic.sample_valid_poses(val, m, B, seed=1000, reachable=reach)
+    goals = synthetic.sample_valid_poses(val, m, B, seed=2000, reachable=reach)
+    seeds = np.arange(B, dtype=np.uint64)
+    batch = pa.HybridAStarBatch(val, max_batch=B, max_nodes=81920, search_rows=1024)
+    batch.initialize()
+    want = batch.search_batch(starts, goals, seeds)
+    fields = ("status", "n_expanded", "n_nodes", "n_path", "n_rng_draws", "n_rs_attempts", "n_state_checks", "n_path_checks")
+    want_a = np.array([[getattr(r, f) for f in fields] for r in want], dtype=np.int64)
+    want_cost = np.array([r.cost for r in want])
+    table = batch.nonholo_table()
+    batch.close()
+    pipe = pa.HybridAStarPipeline(val, capacity=3 * B, max_nodes=81920)
+    pipe.initialize(table)
+    first, submitted, done, bad = None, 0, 0, []
+    t0 = time.time()
+    while done < rounds * B:
+        if submitted < rounds * B and pipe.free_slots() >= B:
+            tickets = pipe.submit(starts, goals, seeds)
+            assert len(tickets) == B
+            first = int(tickets[0]) if first is None else first
+            submitted += B
+        tickets, res = pipe.poll_array(8192)
+        if len(tickets):
+            q = (tickets.astype(np.int64) - first) % B
+            got = np.column_stack([res[f].astype(np.int64) for f in fields])
+            wrong = (got != want_a[q]).any(axis=1) | ((res["status"] == 0) & (res["cost"] != want_cost[q]))
+            bad.extend(int(x) for x in q[wrong])
+            done += len(tickets)
+        else:
+            time.sleep(0.0005)
+        assert time.time() - t0 < 300, "pipeline stalled: %d of %d" % (done, rounds * B)
+    assert not bad, "%d results differ from the batch planner's, queries %s" % (len(bad), sorted(set(bad))[:20])
+    pipe.close()

@@ -162,3 +162,46 @@ def test_pipeline_under_dribbling_submissions_and_short_idle_timeout(monkeypatch
     assert pipe.in_flight() == 0
     pipe.close()
     batch.close()
+
+
+def test_pipeline_replay_with_queued_launches_and_urgent_slots_recycled_early(monkeypatch):
+    """Order of work must not touch results.  With the urgent ring an urgent slot is built by whatever wavefront launch is running, searched,
+    polled and refilled before its own launch -- queued behind several others -- reaches its list entry: that stale entry must not claim
+    the refilled slot (entries and claim words carry the slot's generation), and a launch reads goal poses written after it began
+    (agent-scope loads).  A first version without these two guards built about one field in 4096 for a slot's previous goal at
+    bench.py's scale (bench.py checks every run: `replay_consistent`; tests/test_gpu_fullsize.py repeats its workload).  Here: six
+    submissions stay queued, a third of the queries are urgent, and 40 rounds replay the same 384 queries."""
+    import pathplanning_amd as pa
+    monkeypatch.setenv("PP_PIPE_URGENT_CLEARANCE", "3.0")
+    w, ms, val, ctx = make_pair(512, 12, 1)
+    rng = np.random.RandomState(9)
+    n, rounds = 384, 40
+    starts, goals = valid_random_poses(rng, w, n), valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 31
+    batch = pa.HybridAStarBatch(val, max_batch=n, max_nodes=65536, search_rows=256)
+    batch.initialize()
+    want = batch.search_batch(starts, goals, seeds)
+    want_a = np.array([(r.status, r.n_expanded, r.n_nodes, r.n_rng_draws, r.n_state_checks, r.n_path_checks) for r in want], dtype=np.int64)
+    pipe = pa.HybridAStarPipeline(val, capacity=6 * n, max_nodes=65536, search_rows=512)
+    pipe.initialize(batch.nonholo_table())
+    first, submitted, done, bad = None, 0, 0, []
+    t0 = time.time()
+    while done < rounds * n:
+        if submitted < rounds * n and pipe.free_slots() >= n:
+            tickets = pipe.submit(starts, goals, seeds)
+            assert len(tickets) == n
+            first = int(tickets[0]) if first is None else first
+            submitted += n
+        tickets, res = pipe.poll_array(4096)
+        if len(tickets):
+            q = (tickets.astype(np.int64) - first) % n
+            got = np.column_stack([res[f].astype(np.int64) for f in ("status", "n_expanded", "n_nodes", "n_rng_draws", "n_state_checks", "n_path_checks")])
+            bad.extend(int(x) for x in q[(got != want_a[q]).any(axis=1)])
+            done += len(tickets)
+        else:
+            time.sleep(0.0005)
+        assert time.time() - t0 < 300, "pipeline stalled: %d of %d" % (done, rounds * n)
+    assert not bad, "queries whose result differs from the batch planner's: %s" % sorted(set(bad))[:20]
+    assert pipe.in_flight() == 0
+    pipe.close()
+    batch.close()
