@@ -400,6 +400,11 @@ def main():
         # the dominant one is the one with more busy time per step
         wf_busy_per_step = pipe_kernel["wavefront_ms_total"] / args.steps
         roofs["k_wavefront"]["busy_ms_per_step"] = wf_busy_per_step
+        # launches on the two wavefront streams overlap and share the chip: `achieved` is per launch as the contract defines it (bytes of a
+        # launch / its own duration); all launches in flight together move `achieved_all_launches`
+        in_flight = pipe_kernel["wavefront_ms_total"] / (elapsed * 1e3)
+        roofs["k_wavefront"]["launches_in_flight"] = in_flight
+        roofs["k_wavefront"]["achieved_all_launches"] = wf_gbs * max(1.0, in_flight)
         roofs["search"]["busy_ms_per_step"] = elapsed * 1e3 / args.steps
         roof = roofs["k_wavefront"] if wf_busy_per_step >= elapsed * 1e3 / args.steps else roofs["search"]
     else:

@@ -91,6 +91,9 @@ struct WavefrontPublish {
 	unsigned long long readyMask = 0;        // ring size - 1 (a power of two)
 	int* goalCounter = nullptr;              // the launch's goal counter when it is not the word behind the error flag (the pipeline keeps
 	                                         // the error flag in pinned host memory, where no device atomic should go)
+	int* exitCounter = nullptr;              // != nullptr: the last workgroup to leave sets goalCounter (and this word) back to 0 for the stream's next
+	                                         // launch -- a 4-byte memset in front of every launch is a kernel that waits tens of ms for a free
+	                                         // slot on a GPU filled with long-running workgroups
 	// Goals that should not wait for their launch's turn (pp_pipeline.hpp, "urgent"): a ring of stamped slot numbers shared by ALL launches of a
 	// pipeline -- a workgroup of any launch in flight serves it before it takes the next goal of its own list -- and one claim word per slot
 	// (generation << 1 -> generation << 1 | 1 by whoever builds the slot's field: a slot sits in its launch's list AND, if urgent, in the ring;

@@ -37,36 +37,47 @@ __global__ void __launch_bounds__(256) k_pipe_scatter(int n, const int32_t* __re
 	unsigned long long* __restrict__ urgent, unsigned long long urgentMask, int* __restrict__ claimed)
 {
 	const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-	if (i >= n)
-		return;
-	const uint32_t entry = (uint32_t)slotList[i]; // slot | generation << kSlotBits
-	const size_t s = (size_t)(entry & pph::kSlotMask);
-	for (int k = 0; k < 3; k++) {
-		starts[3 * s + k] = startsIn[3 * (size_t)i + k];
-		goals[3 * s + k] = goalsIn[3 * (size_t)i + k];
+	bool isUrgent = false;
+	uint32_t entry = 0;
+	if (i < n) {
+		entry = (uint32_t)slotList[i]; // slot | generation << kSlotBits
+		const size_t s = (size_t)(entry & pph::kSlotMask);
+		for (int k = 0; k < 3; k++) {
+			starts[3 * s + k] = startsIn[3 * (size_t)i + k];
+			goals[3 * s + k] = goalsIn[3 * (size_t)i + k];
+		}
+		seeds[s] = seedsIn[i];
+		if (claimed) {
+			claimed[s] = (int)((entry >> pph::kSlotBits) << 1); // this generation, not yet claimed (see k_wavefront's hand-out)
+			if (urgentClearance > 0.0f) {
+				float clearance = __builtin_huge_valf();
+				for (int k = 0; k < 2; k++) {
+					const double* p = (k ? goalsIn : startsIn) + 3 * (size_t)i;
+					int row, col;
+					world_to_cell(m, p[0], p[1], row, col);
+					if (inside_map(m, row, col))
+						clearance = fminf(clearance, m.dist[(size_t)row * m.cols + col]);
+					// the edge of the state space confines the car like a wall (the distance grid knows obstacles only)
+					clearance = fminf(clearance, (float)fmin(fmin(p[0] - m.lbx, m.ubx - p[0]), fmin(p[1] - m.lby, m.uby - p[1])));
+				}
+				isUrgent = clearance < urgentClearance;
+			}
+		}
 	}
-	seeds[s] = seedsIn[i];
-	if (!claimed)
-		return;
-	claimed[s] = (int)((entry >> pph::kSlotBits) << 1); // this generation, not yet claimed (see k_wavefront's hand-out)
-	if (!(urgentClearance > 0.0f))
-		return;
-	float clearance = __builtin_huge_valf();
-	for (int k = 0; k < 2; k++) {
-		const double* p = (k ? goalsIn : startsIn) + 3 * (size_t)i;
-		int row, col;
-		world_to_cell(m, p[0], p[1], row, col);
-		if (inside_map(m, row, col))
-			clearance = fminf(clearance, m.dist[(size_t)row * m.cols + col]);
-		// the edge of the state space confines the car like a wall (the distance grid knows obstacles only)
-		clearance = fminf(clearance, (float)fmin(fmin(p[0] - m.lbx, m.ubx - p[0]), fmin(p[1] - m.lby, m.uby - p[1])));
-	}
-	if (clearance < urgentClearance) {
-		// the slot's inputs and claim word reach memory before the entry can be seen (the consumer may belong to a launch that is already running)
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		const unsigned long long t = __hip_atomic_fetch_add(&ctl->urgentTail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(urgent + (t & urgentMask), ((t + 1ull) << 32) | (unsigned long long)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	// The slots' inputs and claim words reach memory before an entry can be seen (the consumer may belong to a launch that is already
+	// running): ONE release per workgroup, behind a barrier that has waited for every thread's stores.  (A release per urgent thread wrote
+	// this XCD's whole L2 back hundreds of times per submission -- the fields under construction are in there -- and made the pipeline
+	// slower the more queries were urgent: 12 % at a third of them, 2x at all of them.)
+	if (__syncthreads_or(isUrgent)) {
+		if (threadIdx.x == 0) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		__syncthreads();
+		if (isUrgent) {
+			const unsigned long long t = __hip_atomic_fetch_add(&ctl->urgentTail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(urgent + (t & urgentMask), ((t + 1ull) << 32) | (unsigned long long)entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
 	}
 }
 
@@ -86,7 +97,8 @@ struct pp_pipeline {
 	int* waveAlive = nullptr;
 	unsigned long long* urgent = nullptr; // ring of urgent slots (k_pipe_scatter -> any running wavefront launch), same size as the ready ring
 	int* claimed = nullptr;               // [capacity] 0 -> 1 by the workgroup that builds the slot's field
-	float urgentClearance = 2.0f;         // [m] queries with a start or goal pose closer than this to an obstacle go through the urgent ring; 0 = none
+	float urgentClearance = -1.0f;        // [m] queries with a start or goal pose closer than this to an obstacle (or the edge) go through the urgent
+	                                      // ring; 0 = none; < 0 = twice the validator's minimum safe radius (2 m with the reference's default)
 	int32_t* slotLists = nullptr; // ring of slot lists, one segment per wavefront launch in flight
 	size_t slotListCap = 0, slotListPos = 0;
 	void* wfWorkspace[kPipeWavefrontStreams] = {};
@@ -306,10 +318,19 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		if (e == hipSuccess)
 			e = hipStreamCreateWithFlags(&P->wfStream[i], hipStreamNonBlocking);
 	}
+	// The wavefront workgroups of a launch in flight stay until its list AND the urgent ring are empty, and launches queue: room on the chip
+	// frees rarely and in bursts.  When it does, the waves that top up the search grid and the scatter kernel of a new submission should get
+	// it before the next wavefront launch's pending workgroups refill the chip: their streams have the highest priority.  A safeguard, not a
+	// measured gain: 14 driver-style runs each way give 16.8-17.4 k with it and 17.0-17.5 k without (PP_PIPE_FLAT_PRIORITY=1); one run in
+	// about forty had come in at 12 k before, consistent results, cause not established (profiles/r03_repeat_runs.txt).
+	int prioLow = 0, prioHigh = 0;
+	(void)hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh);
+	if (getenv("PP_PIPE_FLAT_PRIORITY"))
+		prioHigh = prioLow = 0;
 	for (int i = 0; i < kPipeSearchStreams && e == hipSuccess; i++)
-		e = hipStreamCreateWithFlags(&P->searchStream[i], hipStreamNonBlocking);
+		e = hipStreamCreateWithPriority(&P->searchStream[i], hipStreamNonBlocking, prioHigh);
 	if (e == hipSuccess)
-		e = hipStreamCreateWithFlags(&P->ctlStream, hipStreamNonBlocking);
+		e = hipStreamCreateWithPriority(&P->ctlStream, hipStreamNonBlocking, prioHigh);
 	if (e == hipSuccess)
 		e = hipEventCreateWithFlags(&P->evIngest, hipEventDisableTiming);
 	if (e == hipSuccess)
@@ -435,22 +456,22 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	PP_HIP_TRY(hipMemcpyAsync(listDev, stage, (size_t)k * 4, hipMemcpyHostToDevice, P->ctlStream));
 	pl->args.m = pl->map->view();
 	hipLaunchKernelGGL(k_pipe_scatter, dim3((k + 255) / 256), dim3(256), 0, P->ctlStream, k, listDev, starts_dev, goals_dev, seeds_dev, pl->dStarts, pl->dGoals, pl->dSeeds, pl->args.m,
-		P->urgentClearance, P->ctl, P->urgent, P->readyMask, P->claimed);
+		P->urgentClearance < 0.0f ? 2.0f * pl->args.m.minSafeRadius : P->urgentClearance, P->ctl, P->urgent, P->readyMask, P->claimed);
 	PP_HIP_TRY(hipGetLastError());
 	PP_HIP_TRY(hipEventRecord(P->evIngest, P->ctlStream));
-	PP_HIP_TRY(hipStreamSynchronize(P->ctlStream));
+	PP_HIP_TRY(hipStreamSynchronize(P->ctlStream)); // (measured: skipping it -- a caller that keeps its arrays alive -- changes nothing, 17.1 k either way)
 	// ---- ObstaclesHeuristic::Update for every goal (hybrid_a_star.cpp:249); each finished slot is appended to the ready ring
 	PP_HIP_TRY(hipStreamWaitEvent(w, P->evIngest, 0));
-	PP_HIP_TRY(hipMemsetAsync(wctl + 1, 0, 4, w)); // this launch's goal counter
 	pl->args.m = pl->map->view();
 	pph::WavefrontPublish pub;
 	pub.slotList = listDev;
 	pub.readyTail = &P->ctl->readyTail;
 	pub.ready = P->ready;
 	pub.readyMask = P->readyMask;
-	pub.goalCounter = wctl + 1;
+	pub.goalCounter = wctl + 1; // 0 at creation; the last workgroup of every launch sets it back
+	pub.exitCounter = wctl + 2;
 	pub.claimed = P->claimed;
-	if (P->urgentClearance > 0.0f) {
+	if (P->urgentClearance != 0.0f) {
 		pub.urgent = P->urgent;
 		pub.urgentHead = &P->ctl->urgentHead;
 		pub.urgentMask = P->readyMask;

@@ -586,6 +586,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 	int tagGoal = -1; // goal whose fallback rounds the tag grid currently describes (it is cleared lazily)
 	// goals are handed out dynamically: a workgroup that finishes early takes the next one (balanced tail)
 	int pendingSlot = -1; // pipeline use: field slot of the goal this workgroup has just finished, not yet announced
+	bool ringTurn = true; // (thread 0) pipeline use: does the urgent ring have the first look at the next hand-out?
 	for (;;) {
 		__syncthreads(); // (every wave's stores of the previous goal have completed: the barrier's release waits for them)
 		if (tid == 0) {
@@ -605,23 +606,26 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 			// polled and refilled before its own launch reaches its list entry -- carries a generation that no longer matches and is skipped
 			// (without the generation such an entry claims the refilled slot: a goal written AFTER this launch began, reached through the
 			// list path; a version that did so, with the pose read through the caches, built ~1 field in 4096 for the slot's previous goal).
-			int next = -1;
-			if (pub.urgent) {
+			// The ring has the first look on every other hand-out only: goals of the lists keep moving whatever share of the queries is urgent
+			// (with the ring always first, a third of the queries urgent cost 12 % of the throughput and half of them 36 %: the later
+			// submissions' urgent goals kept overtaking the earlier submissions' ordinary ones, whose slots then stayed taken).
+			auto take_urgent = [&]() -> int {
 				for (;;) {
 					unsigned long long h = __hip_atomic_load(pub.urgentHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					const unsigned long long e = __hip_atomic_load(pub.urgent + (h & pub.urgentMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					if ((uint32_t)(e >> 32) != (uint32_t)(h + 1ull))
-						break; // nothing there (or reserved and not yet written: its own launch will come to it)
+						return -1; // nothing there (or reserved and not yet written: its own launch will come to it)
 					if (!__hip_atomic_compare_exchange_strong(pub.urgentHead, &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 						continue; // another workgroup took it: look again
 					const int slot = (int)((uint32_t)e & pph::kSlotMask);
 					int expect = (int)(((uint32_t)e >> pph::kSlotBits) << 1);
-					if (__hip_atomic_compare_exchange_strong(pub.claimed + slot, &expect, expect | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-						next = slot;
-						break;
-					}
+					if (__hip_atomic_compare_exchange_strong(pub.claimed + slot, &expect, expect | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+						return slot;
 				}
-			}
+			};
+			int next = -1;
+			if (pub.urgent && ringTurn)
+				next = take_urgent();
 			while (next < 0) {
 				const int gi = atomicAdd(goalCounter, 1);
 				if (gi >= nGoals)
@@ -636,6 +640,10 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 						next = slot;
 				}
 			}
+			// (A workgroup leaves when its launch's list has run out, whatever the ring holds: by then every slot of its own submission is
+			// claimed -- the list names them all -- and what is left in the ring belongs to later submissions, whose launches follow.  Workgroups
+			// that stayed for the ring kept their launch alive with ever fewer of them, and the stream's next launch waiting behind it.)
+			ringTurn = !ringTurn;
 			s_goal = next;
 			// the goal's cell.  In the pipeline the pose may have been written while this launch was running (urgent ring): it is read with
 			// agent-scope loads, which do not look at this XCD's possibly stale copy of the line -- cheaper than an acquire fence per goal,
@@ -1262,6 +1270,14 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				prof[(size_t)g * WP_COUNT + i] = ph[i];
 	}
 #undef WF_STAMP
+	if (pub.exitCounter && tid == 0) {
+		// (this workgroup's last look at the goal counter precedes its exit count)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		if (__hip_atomic_fetch_add(pub.exitCounter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+			__hip_atomic_store(goalCounter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(pub.exitCounter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
 	// ---- optional epilogue for the planner: the LAST workgroup to run out of goals orders the queries by decreasing
 	// field value at their start pose (probable longest search first; +inf = unreachable first) for the search kernel's
 	// hand-out -- no extra launch that would queue behind persistent grids.  nGoals <= WF_LCAP.
