@@ -341,6 +341,10 @@ int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_checke
  * its own ends, slots are recycled as results are polled.  No batch boundary: a query that exhausts the lattice (~1 s) holds one
  * row, not a batch's 17 GB of fields.  Results per query are exactly those of pp_planner_search_batch (same kernels' device code).
  * log_expansions != 0 keeps the expansion log per slot (parity tests; 4 B x max_nodes_per_query per slot).
+ * 4 <= capacity < 2^20.  The ORDER in which fields are built is the pipeline's own (never a result): queries with a start or goal pose
+ * closer than twice the validator's minimum safe radius to an obstacle or to the edge of the state space -- the ones that tend to
+ * exhaust the lattice and end a run -- are built ahead of the submissions queued before them (PP_PIPE_URGENT_CLEARANCE=<m>, 0 = in
+ * order of submission).  Results arrive in completion order either way.
  * Not thread-safe per pipeline.  Set GPU_MAX_HW_QUEUES >= 8 before the HIP runtime starts: the pipeline's kernels run on seven
  * streams, and two streams that share a hardware queue serialise (the grid then falls back on its idle time-out, PP_PIPE_IDLE_MS). */
 typedef struct pp_pipeline pp_pipeline;
