@@ -372,6 +372,25 @@ def main():
     fused_ms = ctx.timer_stop() / reps
     del poses, out
 
+    # ---- the wavefront kernel with the chip to itself (one launch, the step's 4096 goals, row-major fields): the kernel's own rate, next to
+    # the per-launch figure of the timed region, where launches overlap and share the chip with the search grid
+    wf_alone_ms = None
+    if pipeline_mode and rank == 0 and not args.no_cpu_baseline:
+        try:
+            from pathplanning_amd.planner import ObstaclesHeuristic
+            out_f = torch.empty((B, ms.rows * ms.cols), dtype=torch.float32, device=dev)
+            oh = ObstaclesHeuristic(ms)
+            for _ in range(2):
+                oh.update_dev(goals[:, :2], out_f)
+            ctx.synchronize()
+            ctx.timer_start()
+            oh.update_dev(goals[:, :2], out_f)
+            wf_alone_ms = float(ctx.timer_stop())
+            del out_f
+        except Exception as e:  # (memory: the pipeline's slots are still allocated)
+            wf_alone_ms = None
+            print("stand-alone wavefront measurement skipped: %s" % e, file=sys.stderr)
+
     # ---- roofline of the dominant kernel of the step
     search_kernel = "k_hybrid_search_rows" if lanes[0][3].search_rows else "k_hybrid_search"
     wf = float(np.mean(wf_ms))
@@ -405,6 +424,9 @@ def main():
         in_flight = pipe_kernel["wavefront_ms_total"] / (elapsed * 1e3)
         roofs["k_wavefront"]["launches_in_flight"] = in_flight
         roofs["k_wavefront"]["achieved_all_launches"] = wf_gbs * max(1.0, in_flight)
+        if wf_alone_ms:
+            alone_gbs = B * cells * WAVEFRONT_BYTES_PER_CELL / (wf_alone_ms * 1e-3) / 1e9
+            roofs["k_wavefront"]["alone"] = dict(ms_per_launch=wf_alone_ms, goals=B, achieved=alone_gbs, frac=alone_gbs / HBM_PEAK_GBS)
         roofs["search"]["busy_ms_per_step"] = elapsed * 1e3 / args.steps
         roof = roofs["k_wavefront"] if wf_busy_per_step >= elapsed * 1e3 / args.steps else roofs["search"]
     else:
