@@ -220,10 +220,18 @@ int pp_nonholo_build(pp_ctx* ctx, const double lower[3], const double upper[3], 
 
 /* ---- a8: ObstaclesHeuristic::Update (algo/heuristics.cpp:106-153) ----------
  * One wavefront per goal; cost_dev is [n_goals][rows*cols] float, +inf where the
- * reference leaves the cell unexplored.  Exact reference order (first discovery,
- * no relaxation, LIFO ties).  goal_xy: world positions. */
+ * reference leaves the cell unexplored.  The reference's values bit for bit (first discovery,
+ * no relaxation, LIFO ties): built as the fixed point those rules define, one wave per goal over
+ * 64 x 64-cell tiles (pp_wavefront_tiles.hip); a goal whose value could depend on the pop order among
+ * equal costs is detected and rebuilt in the reference's own order (pp_wavefront.hip), as is every goal
+ * when PP_WF_TILES=0 is in the environment.  goal_xy: world positions. */
 int pp_obstacle_heuristic_dev(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev);
 int pp_obstacle_heuristic(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_host);
+/* Diagnostics of the tile form: the same fields into cost_dev ([n_goals][rows*cols]), plus 8 words
+ * {goals built, tile visits, bucket rounds, candidate passes, cells settled, goals handed to the ordered kernel,
+ * summed wave cycles, tiles per goal} and the launch's duration in ms (HIP events on the context's stream).
+ * PP_ERR_INVALID when the tile form is switched off or does not support the map. */
+int pp_obstacle_heuristic_tiles_stats(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev, uint64_t stats_host[8], float* ms_out);
 /* Diagnostics: stamped build of the wavefront kernel; per goal 20 words {init, min, partition, sort, offer, push,
  * tail cycles, rounds, sum of window sizes, rounds with the open list in HBM, fallback rounds, push cycles of fallback rounds,
  * offer sub-phases: store wait, neighbourhood loads, candidate count, whole offer up to the end of insertion,

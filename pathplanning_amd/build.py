@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libpphip.so")
-SOURCES = ["pp_capi.hip", "pp_kernels_basic.hip", "pp_paths.hip", "pp_gvd.hip", "pp_wavefront.hip", "pp_planner.hip", "pp_rrt.hip", "pp_grid_astar.hip"]
+SOURCES = ["pp_capi.hip", "pp_kernels_basic.hip", "pp_paths.hip", "pp_gvd.hip", "pp_wavefront.hip", "pp_wavefront_tiles.hip", "pp_planner.hip", "pp_rrt.hip", "pp_grid_astar.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "pp_hip.h")]
 # -ffp-contract=off: no FMA contraction -- discrete outputs must match the CPU reference bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]

@@ -25,6 +25,7 @@ using namespace pph;
 ppd::MapView pp_map::view() const
 {
 	ppd::MapView v;
+	int nWordRows_unused = 0;
 	v.rows = desc.rows;
 	v.cols = desc.cols;
 	v.res = desc.resolution;
@@ -45,7 +46,23 @@ ppd::MapView pp_map::view() const
 	v.pathcost = pathcost;
 	v.occ8 = occ8;
 	v.validBits = validBits;
+	v.occBits = occBits;
+	pph::occ_bits_dims(desc.rows, desc.cols, v.occWpr, nWordRows_unused);
 	return v;
+}
+
+int pph::refresh_occupancy_views(pp_map* map, hipStream_t s)
+{
+	const size_t n = map->cells();
+	if (!map->occ8)
+		PP_HIP_TRY(hipMalloc((void**)&map->occ8, n));
+	int wpr = 0, nWordRows = 0;
+	pph::occ_bits_dims(map->desc.rows, map->desc.cols, wpr, nWordRows);
+	if (!map->occBits)
+		PP_HIP_TRY(hipMalloc((void**)&map->occBits, (size_t)wpr * nWordRows * 8));
+	PP_HIP_TRY(pph::launch_occ_to_u8(s, map->occ32, map->occ8, (int64_t)n));
+	PP_HIP_TRY(pph::launch_occ_bits(s, map->occ8, map->desc.rows, map->desc.cols, map->occBits));
+	return PP_OK;
 }
 
 namespace {
@@ -106,6 +123,8 @@ void map_release(pp_map* map)
 		(void)hipFree(map->pathcost);
 	if (map->occ8)
 		(void)hipFree(map->occ8);
+	if (map->occBits)
+		(void)hipFree(map->occBits);
 	if (map->validBits)
 		(void)hipFree(map->validBits);
 	void* more[] = { map->occ32, map->obstLabel[0], map->obstLabel[1], map->voroLabel[0], map->voroLabel[1], map->voroD2, map->voroEdge, map->gvdFlag };
@@ -272,8 +291,6 @@ int pp_map_upload_occupancy(pp_map* map, const int32_t* occ_host)
 	const size_t n = map->cells();
 	if (!map->occ32) // kept: pp_map_update_gvd builds the distance / Voronoi / path-cost fields from it
 		PP_HIP_TRY(hipMalloc((void**)&map->occ32, n * sizeof(int32_t)));
-	if (!map->occ8)
-		PP_HIP_TRY(hipMalloc((void**)&map->occ8, n));
 	PP_HIP_TRY(hipMemcpyAsync(map->occ32, occ_host, n * sizeof(int32_t), hipMemcpyHostToDevice, map->ctx->stream));
 	// for the reference-order field update (pp_map_update_gvd_ex) a whole-grid upload is "an empty map, then every occupied cell in
 	// row-major order": the reference has no such entry point (its cells only arrive through AddObstacle), so this order is ours
@@ -285,7 +302,8 @@ int pp_map_upload_occupancy(pp_map* map, const int32_t* occ_host)
 			map->journal.push_back((int32_t)i);
 			map->journal.push_back(occ_host[i]);
 		}
-	PP_HIP_TRY(launch_occ_to_u8(map->ctx->stream, map->occ32, map->occ8, (int64_t)n));
+	if (int rc = pph::refresh_occupancy_views(map, map->ctx->stream))
+		return rc;
 	PP_HIP_TRY(hipStreamSynchronize(map->ctx->stream));
 	return PP_OK;
 }
@@ -708,16 +726,75 @@ int pp_obstacle_heuristic_dev(pp_map* map, int32_t n_goals, const double* goal_x
 	const int resident = wavefront_resident_blocks();
 	int nSlots = n_goals < resident ? n_goals : resident;
 	const int64_t wsb = wavefront_workspace_bytes(map->desc.rows, map->desc.cols);
-	DevBuf ws, dc, derr;
+	const bool tiles = map->occBits && wavefront_tiles_enabled() && wavefront_tiles_supported(map->desc.rows, map->desc.cols);
+	if (tiles && nSlots > 16)
+		nSlots = 16; // (the ordered kernel only takes the goals the tile form hands over)
+	DevBuf ws, dc, derr, dtiles;
 	PP_HIP_TRY(ws.alloc((size_t)wsb * nSlots));
 	PP_HIP_TRY(dc.alloc((size_t)n_goals * 4));
 	PP_HIP_TRY(derr.alloc(8));
+	PP_HIP_TRY(dtiles.alloc(64 + (size_t)n_goals * 4));
 	PP_HIP_TRY(hipMemsetAsync(derr.p, 0, 8, s));
+	PP_HIP_TRY(hipMemsetAsync(dtiles.p, 0, 64, s));
 	PP_HIP_TRY(hipMemcpyAsync(dc.p, cells.data(), (size_t)n_goals * 4, hipMemcpyHostToDevice, s));
-	PP_HIP_TRY(launch_wavefront(s, map->view(), n_goals, dc.as<int32_t>(), cost_dev, ws.p, wsb, nSlots, derr.as<int32_t>()));
+	WavefrontPublish pub;
+	if (tiles) {
+		pub.tilesCtl = dtiles.as<int>();
+		pub.tilesFallback = dtiles.as<int32_t>() + 16;
+	}
+	PP_HIP_TRY(launch_wavefront(s, map->view(), n_goals, dc.as<int32_t>(), cost_dev, ws.p, wsb, nSlots, derr.as<int32_t>(), nullptr, false, nullptr, false, nullptr, nullptr, nullptr,
+		nullptr, pub));
 	int32_t err = 0;
 	PP_HIP_TRY(hipMemcpyAsync(&err, derr.p, 4, hipMemcpyDeviceToHost, s));
 	PP_HIP_TRY(hipStreamSynchronize(s));
+	if (err) {
+		set_error("obstacle-heuristic open list exceeded its workspace");
+		return PP_ERR_CAPACITY;
+	}
+	return PP_OK;
+}
+
+int pp_obstacle_heuristic_tiles_stats(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev, uint64_t stats_host[8], float* ms_out)
+{
+	if (check_map(map, false) || !map->occ8 || n_goals <= 0 || !goal_xy_host || !cost_dev || !stats_host) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	if (!map->occBits || !wavefront_tiles_enabled() || !wavefront_tiles_supported(map->desc.rows, map->desc.cols)) {
+		set_error("the tile form of the wavefront is switched off (PP_WF_TILES=0) or does not support this map size");
+		return PP_ERR_INVALID;
+	}
+	PP_HIP_TRY(hipSetDevice(map->ctx->device));
+	hipStream_t s = map->ctx->stream;
+	std::vector<int32_t> cells;
+	goal_cells(map, n_goals, goal_xy_host, cells);
+	const int nSlots = n_goals < 16 ? n_goals : 16;
+	const int64_t wsb = wavefront_workspace_bytes(map->desc.rows, map->desc.cols);
+	DevBuf ws, dc, derr, dtiles, dstats;
+	PP_HIP_TRY(ws.alloc((size_t)wsb * nSlots));
+	PP_HIP_TRY(dc.alloc((size_t)n_goals * 4));
+	PP_HIP_TRY(derr.alloc(8));
+	PP_HIP_TRY(dtiles.alloc(64 + (size_t)n_goals * 4));
+	PP_HIP_TRY(dstats.alloc(64));
+	PP_HIP_TRY(hipMemsetAsync(derr.p, 0, 8, s));
+	PP_HIP_TRY(hipMemsetAsync(dtiles.p, 0, 64, s));
+	PP_HIP_TRY(hipMemsetAsync(dstats.p, 0, 64, s));
+	PP_HIP_TRY(hipMemcpyAsync(dc.p, cells.data(), (size_t)n_goals * 4, hipMemcpyHostToDevice, s));
+	WavefrontPublish pub;
+	pub.tilesCtl = dtiles.as<int>();
+	pub.tilesFallback = dtiles.as<int32_t>() + 16;
+	pub.tilesStats = dstats.as<unsigned long long>();
+	PP_HIP_TRY(hipEventRecord(map->ctx->ev0, s));
+	PP_HIP_TRY(launch_wavefront(s, map->view(), n_goals, dc.as<int32_t>(), cost_dev, ws.p, wsb, nSlots, derr.as<int32_t>(), nullptr, false, nullptr, false, nullptr, nullptr, nullptr,
+		nullptr, pub));
+	PP_HIP_TRY(hipEventRecord(map->ctx->ev1, s));
+	int32_t err = 0;
+	PP_HIP_TRY(hipMemcpyAsync(&err, derr.p, 4, hipMemcpyDeviceToHost, s));
+	PP_HIP_TRY(hipMemcpyAsync(stats_host, dstats.p, 64, hipMemcpyDeviceToHost, s));
+	PP_HIP_TRY(hipStreamSynchronize(s));
+	stats_host[7] = (uint64_t)((map->desc.rows + 63) / 64) * (uint64_t)((map->desc.cols + 63) / 64);
+	if (ms_out)
+		PP_HIP_TRY(hipEventElapsedTime(ms_out, map->ctx->ev0, map->ctx->ev1));
 	if (err) {
 		set_error("obstacle-heuristic open list exceeded its workspace");
 		return PP_ERR_CAPACITY;

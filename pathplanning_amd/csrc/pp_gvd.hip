@@ -487,9 +487,8 @@ int pp_map_set_cells(pp_map* map, int64_t n_cells, const int32_t* cells_host, in
 		if (e != hipSuccess)
 			return pph::hip_fail(e, "pp_map_set_cells");
 	}
-	if (!map->occ8)
-		PP_HIP_TRY(hipMalloc((void**)&map->occ8, n));
-	PP_HIP_TRY(pph::launch_occ_to_u8(s, map->occ32, map->occ8, (int64_t)n));
+	if (int rc = pph::refresh_occupancy_views(map, s))
+		return rc;
 	PP_HIP_TRY(hipStreamSynchronize(s));
 	return PP_OK;
 }

@@ -102,7 +102,27 @@ struct WavefrontPublish {
 	unsigned long long* urgentHead = nullptr; // entries claimed so far (absolute)
 	unsigned long long urgentMask = 0;
 	int* claimed = nullptr;
+	// The tile form of the wavefront (pp_wavefront_tiles.hip) builds the fields when the caller provides its control words; the goals it cannot
+	// certify (a tie of its fixed-point equation, a run that does not settle) are rebuilt by the ordered kernel, launched behind it on the same stream.
+	int* tilesCtl = nullptr;          // >= 8 ints, zero at allocation (the kernels set them back): tile goal counter, exit counter, handed-over count, ordered goal counter, exit counter
+	int32_t* tilesFallback = nullptr; // [>= number of goals a launch may take] the handed-over goals
+	unsigned long long* tilesStats = nullptr; // optional, 8 words: goals, tile visits, rounds, candidate passes, cells, handed over, wave cycles
+	// (set by launch_wavefront for the ordered kernel's launch over the handed-over goals)
+	const int* nGoalsDev = nullptr;   // the launch's number of goals lives on the device
+	int* resetOnExit = nullptr;       // one more word the last workgroup sets back to 0
+	bool agentPoseLoads = false;      // read goal poses with agent-scope loads although no claim words are in use
 };
+/// occupancy bits of the tile form (MapView::occBits): words per row and rows of the padded word grid
+void occ_bits_dims(int rows, int cols, int& wpr, int& nWordRows);
+hipError_t launch_occ_bits(hipStream_t s, const uint8_t* occ8, int rows, int cols, uint64_t* bits);
+bool wavefront_tiles_supported(int rows, int cols);
+int wavefront_tiles_resident_blocks(int rows, int cols);
+hipError_t warm_up_wavefront_tiles(hipStream_t s, const ppd::MapView& m, int* ctlDev);
+hipError_t launch_wavefront_tiles(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, bool tiledOut, const double* goalPosesDev,
+	const double* orderStartsDev, float* orderKeysDev, const WavefrontPublish& pub);
+hipError_t launch_order_by_key(hipStream_t s, int n, const float* keysDev, int32_t* orderOutDev);
+/// is the tile form in use (PP_WF_TILES=0 switches it off: every goal through the ordered kernel)
+bool wavefront_tiles_enabled();
 hipError_t launch_wavefront(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, void* workspaceDev,
 	int64_t workspaceBytesPerSlot, int nSlots, int32_t* errorFlagDev, unsigned long long* profDev = nullptr, bool tiledOut = false,
 	const double* goalPosesDev = nullptr, bool countersZeroed = false, const double* orderStartsDev = nullptr, int32_t* orderOutDev = nullptr,
@@ -115,6 +135,8 @@ struct pp_map;
 namespace pph {
 struct GvdReference;
 void gvd_reference_free(pp_map* map); // pp_gvd.hip
+/// occ8 and occBits from occ32 (every writer of the occupancy grid ends here)
+int refresh_occupancy_views(pp_map* map, hipStream_t s);
 void ctx_release(pp_ctx* ctx); // drops one reference, frees at zero
 void map_release(pp_map* map);
 } // namespace pph
@@ -140,6 +162,7 @@ struct pp_map {
 	float* pathcost = nullptr;
 	uint8_t* occ8 = nullptr;
 	uint32_t* validBits = nullptr; // one bit per cell: dist >= minSafeRadius
+	uint64_t* occBits = nullptr;   // occupancy as padded bit rows (MapView::occBits), rebuilt whenever occ8 is
 	// map authoring / field construction on the device (pp_gvd.hip)
 	int32_t* occ32 = nullptr;      // occupancy ids as the reference holds them (-1 free)
 	uint32_t* obstLabel[2] = { nullptr, nullptr }; // nearest obstacle cell (row << 16 | col), ping-pong

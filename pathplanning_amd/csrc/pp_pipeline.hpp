@@ -102,7 +102,8 @@ struct pp_pipeline {
 	int32_t* slotLists = nullptr; // ring of slot lists, one segment per wavefront launch in flight
 	size_t slotListCap = 0, slotListPos = 0;
 	void* wfWorkspace[kPipeWavefrontStreams] = {};
-	int32_t* wfCtl[kPipeWavefrontStreams] = {}; // {error flag, goal counter} per wavefront stream
+	int32_t* wfCtl[kPipeWavefrontStreams] = {}; // per wavefront stream: {error flag, goal counter, exit counter, -, then the tile form's eight control words}
+	int32_t* wfFallback[kPipeWavefrontStreams] = {}; // per wavefront stream, [capacity]: the goals the tile form hands to the ordered kernel
 	// pinned host
 	PipeDone* done = nullptr;
 	unsigned long long doneMask = 0;
@@ -162,7 +163,7 @@ void free_pipeline(pp_pipeline* P)
 			if (t.b)
 				(void)hipEventDestroy(t.b);
 		}
-	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->urgent, P->claimed, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfWorkspace[2], P->wfWorkspace[3], P->wfCtl[0], P->wfCtl[1], P->wfCtl[2], P->wfCtl[3] };
+	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->urgent, P->claimed, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfWorkspace[2], P->wfWorkspace[3], P->wfCtl[0], P->wfCtl[1], P->wfCtl[2], P->wfCtl[3], P->wfFallback[0], P->wfFallback[1], P->wfFallback[2], P->wfFallback[3] };
 	for (void* q : dev)
 		if (q)
 			(void)hipFree(q);
@@ -312,9 +313,11 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	for (int i = 0; i < P->nWf && e == hipSuccess; i++) {
 		e = hipMalloc(&P->wfWorkspace[i], (size_t)pl->wfBytesPerSlot * pl->wfSlots);
 		if (e == hipSuccess)
-			e = hipMalloc((void**)&P->wfCtl[i], 32);
+			e = hipMalloc((void**)&P->wfCtl[i], 64);
 		if (e == hipSuccess)
-			e = hipMemset(P->wfCtl[i], 0, 32);
+			e = hipMemset(P->wfCtl[i], 0, 64);
+		if (e == hipSuccess)
+			e = hipMalloc((void**)&P->wfFallback[i], (size_t)capacity * 4);
 		if (e == hipSuccess)
 			e = hipStreamCreateWithFlags(&P->wfStream[i], hipStreamNonBlocking);
 	}
@@ -450,6 +453,7 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	// ---- inputs into their slots: on the control stream (never busy for long), so the caller's arrays are free when this returns
 	hipStream_t const w = P->wfStream[P->nextWf];
 	int32_t* const wctl = P->wfCtl[P->nextWf];
+	int32_t* const wfb = P->wfFallback[P->nextWf];
 	int32_t* const werr = P->errFlags + P->nextWf; // (pinned host memory: the kernel's plain store reaches it, poll reads it)
 	void* const wws = P->wfWorkspace[P->nextWf];
 	P->nextWf = (P->nextWf + 1) % P->nWf;
@@ -471,6 +475,8 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	pub.goalCounter = wctl + 1; // 0 at creation; the last workgroup of every launch sets it back
 	pub.exitCounter = wctl + 2;
 	pub.claimed = P->claimed;
+	pub.tilesCtl = wctl + 8;
+	pub.tilesFallback = wfb;
 	if (P->urgentClearance != 0.0f) {
 		pub.urgent = P->urgent;
 		pub.urgentHead = &P->ctl->urgentHead;

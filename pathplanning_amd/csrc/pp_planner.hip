@@ -1183,6 +1183,8 @@ struct pp_planner {
 	int64_t wfBytesPerSlot = 0;
 	int wfSlots = 0;
 	int32_t* wfError = nullptr;
+	int* tilesCtl = nullptr;          // control words of the tile form of the wavefront (pp_wavefront_tiles.hip; zero at allocation, set back by its kernels)
+	int32_t* tilesFallback = nullptr; // [maxBatch] goals it hands to the ordered kernel
 	Node* nodes = nullptr;
 	HeapEntry* heaps = nullptr;
 	uint32_t* keymaps = nullptr;
@@ -1244,6 +1246,8 @@ int warm_up_kernels(pp_planner* p, pp_map* map)
 	hipError_t e = hipMemsetAsync(ctl, 0, 64, s);
 	if (e == hipSuccess)
 		e = pph::warm_up_wavefront(s, map->view(), ctl);
+	if (e == hipSuccess && map->occBits && pph::wavefront_tiles_supported(map->desc.rows, map->desc.cols))
+		e = pph::warm_up_wavefront_tiles(s, map->view(), (int*)ctl + 8);
 	if (e == hipSuccess) {
 		SearchArgs none = p->args;
 		none.rowsWaves = 0; // every wave of the rows kernel leaves at once
@@ -1322,7 +1326,7 @@ void free_planner(pp_planner* p)
 	for (void* q : postPtrs)
 		if (q)
 			(void)hipFree(q);
-	void* ptrs[] = { p->guardLog, p->guardCount, p->bandMeta, p->bands, p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
+	void* ptrs[] = { p->guardLog, p->guardCount, p->bandMeta, p->bands, p->orderKeys, p->order, p->suspended, p->paths, p->mtStates, p->table, p->costFields, p->wfWorkspace, p->wfError, p->tilesCtl, p->tilesFallback, p->nodes, p->heaps, p->keymaps, p->expanded, p->rsLogs, p->results, p->prof, p->dStarts,
 		p->dGoals, p->dSeeds };
 	for (void* q : ptrs)
 		if (q)
@@ -1533,6 +1537,8 @@ static int create_planner(pp_map* map, const pp_hybrid_params* params, int32_t m
 	alloc((void**)&p->table, tableBytes);
 	alloc((void**)&p->costFields, B * (size_t)A.fieldElems * sizeof(float));
 	alloc((void**)&p->wfWorkspace, (size_t)p->wfBytesPerSlot * p->wfSlots);
+	alloc((void**)&p->tilesCtl, 64);
+	alloc((void**)&p->tilesFallback, B * 4);
 	alloc((void**)&p->wfError, 32); // control block: {wavefront error flag, wavefront goal counter, pass-1 query counter, pass-1 set-aside count,
 	                                // pass-2 record counter, pass-2 set-aside count}
 	// search buffers: one set per resident row (rows kernel) or per query (one-query-per-wave kernel)
@@ -1583,6 +1589,8 @@ static int create_planner(pp_map* map, const pp_hybrid_params* params, int32_t m
 			if (e == hipSuccess)
 				e = hipMalloc(w.first, w.second);
 	}
+	if (e == hipSuccess)
+		e = hipMemset(p->tilesCtl, 0, 64);
 	if (e == hipSuccess)
 		e = hipEventCreate(&p->e0);
 	if (e == hipSuccess)
@@ -1713,10 +1721,14 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 #else
 	constexpr int dbgSkip = 0;
 #endif
-	if (dbgSkip != 1)
+	if (dbgSkip != 1) {
+		pph::WavefrontPublish pub;
+		pub.tilesCtl = planner->tilesCtl;
+		pub.tilesFallback = planner->tilesFallback;
 		PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
-		planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true, ordered ? starts_dev : nullptr, ordered ? planner->order : nullptr,
-		planner->wfError + 6, planner->orderKeys));
+			planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true, ordered ? starts_dev : nullptr, ordered ? planner->order : nullptr,
+			planner->wfError + 6, planner->orderKeys, pub));
+	}
 	PP_HIP_TRY(hipEventRecord(planner->e1, s));
 	const int nDirect = ordered && planner->directCount > 0 && dbgSkip != 2 ? (planner->directCount < n_queries / 2 ? planner->directCount : n_queries / 2) : 0;
 	planner->args.directCount = nDirect;

@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				next = take_urgent();
 			while (next < 0) {
 				const int gi = atomicAdd(goalCounter, 1);
-				if (gi >= nGoals)
+				if (gi >= (pub.nGoalsDev ? *pub.nGoalsDev : nGoals)) // (a count the tile form's launch in front of this one wrote: pp_wavefront_tiles.hip)
 					break;
 				if (!pub.slotList) {
 					next = gi;
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 				int32_t st;
 				if (goalPoses) { // (x, y, theta) triples: WorldPositionToGridCell(bounded), heuristics.cpp:115
 					double px, py;
-					if (pub.claimed) {
+					if (pub.claimed || pub.agentPoseLoads) {
 						px = __hip_atomic_load(goalPoses + 3 * (size_t)next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 						py = __hip_atomic_load(goalPoses + 3 * (size_t)next + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					} else {
@@ -1255,7 +1255,7 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		// (arguments recomputed from the kernel arguments: nothing extra stays live across the round loop for this call)
 		fill_unreached(S.state, state_bytes(m.rows, m.cols) >> 3, state_tiles_per_row(m.cols), m.rows, m.cols, tiledOut, costOut + (int64_t)g * fieldElems, (int)threadIdx.x);
 		__syncthreads();
-		if (orderOut && tid == 0) {
+		if (orderKeys && orderStarts && tid == 0) {
 			// hand-out key of this query: the field value at its start pose, published with a device-scope store (the
 			// workgroup that sorts the keys may sit on another XCD, whose L2 does not see this one's plain stores)
 			int row, col;
@@ -1276,6 +1276,8 @@ __global__ void __launch_bounds__(WF_T, PP_WF_WAVES_PER_SIMD) k_wavefront(MapVie
 		if (__hip_atomic_fetch_add(pub.exitCounter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
 			__hip_atomic_store(goalCounter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			__hip_atomic_store(pub.exitCounter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (pub.resetOnExit)
+				__hip_atomic_store(pub.resetOnExit, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 	// ---- optional epilogue for the planner: the LAST workgroup to run out of goals orders the queries by decreasing
@@ -1344,6 +1346,15 @@ int64_t wavefront_workspace_bytes(int rows, int cols)
 	return (b + 255) / 256 * 256;
 }
 
+bool wavefront_tiles_enabled()
+{
+	static const bool on = [] {
+		const char* e = getenv("PP_WF_TILES");
+		return !(e && e[0] == '0');
+	}();
+	return on;
+}
+
 int wavefront_resident_blocks()
 {
 	int perCu = 0, dev = 0;
@@ -1373,6 +1384,33 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 		return hipSuccess;
 	uint32_t fcap, gcap;
 	wf_caps(m.rows, m.cols, fcap, gcap);
+	if (pub.tilesCtl && pub.tilesFallback && !profDev && m.occBits && wavefront_tiles_enabled() && wavefront_tiles_supported(m.rows, m.cols)) {
+		// The tile form (pp_wavefront_tiles.hip) builds the fields; behind it, on the same stream, the ordered kernel takes the goals it handed
+		// over (their number is a device word: normally 0, and its few workgroups leave at once), then the hand-out order if the planner wants one.
+		hipError_t e = launch_wavefront_tiles(s, m, nGoals, goalCellsDev, costDev, tiledOut, goalPosesDev, orderStartsDev, orderKeysDev, pub);
+		if (e != hipSuccess)
+			return e;
+		WavefrontPublish fb = pub;
+		fb.slotList = pub.tilesFallback; // plain goal / slot numbers: already claimed by the wave that handed them over
+		fb.claimed = nullptr;
+		fb.urgent = nullptr;
+		fb.urgentHead = nullptr;
+		fb.nGoalsDev = pub.tilesCtl + 2;
+		fb.goalCounter = pub.tilesCtl + 3;
+		fb.exitCounter = pub.tilesCtl + 4;
+		fb.resetOnExit = pub.tilesCtl + 2;
+		fb.agentPoseLoads = pub.claimed != nullptr;
+		fb.tilesCtl = nullptr;
+		const int fgrid = nSlots < 16 ? (nSlots < nGoals ? nSlots : nGoals) : (nGoals < 16 ? nGoals : 16);
+		hipLaunchKernelGGL(k_wavefront<false>, dim3(fgrid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
+			(unsigned long long*)nullptr, fb.goalCounter, tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, (int32_t*)nullptr, (int*)nullptr, orderStartsDev ? orderKeysDev : nullptr, fb);
+		e = hipGetLastError();
+		if (e != hipSuccess)
+			return e;
+		if (orderOutDev && orderStartsDev)
+			e = launch_order_by_key(s, nGoals, orderKeysDev, orderOutDev);
+		return e;
+	}
 	int grid = nGoals < nSlots ? nGoals : nSlots;
 	if (const char* e = getenv("PP_WF_GRID")) { // diagnostic: fewer resident workgroups (is a goal's latency independent of its neighbours on the CU?)
 		const int g = atoi(e);

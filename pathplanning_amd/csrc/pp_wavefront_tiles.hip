@@ -1,0 +1,677 @@
+// obst_wavefront, tile form -- ObstaclesHeuristic::Update (algo/heuristics.cpp:106-153) on gfx950 as the FIXED POINT it defines.
+//
+// The reference pops a sorted open list (LIFO among equal costs, utils/frontier.h:39-48,83-91) and never relaxes
+// (heuristics.cpp:137-150): a cell keeps the cost it was given when the FIRST of its neighbours was popped.  Pops are
+// non-decreasing in cost, so that neighbour is the cell's allowed, reached neighbour of smallest cost:
+//     cost[n] = fl(cost[p] + edge(p, n)),   p = argmin { cost[m] : m neighbour of n, move m -> n allowed },        (*)
+// edge = 1.0f or sqrtf(2.0f), "allowed" = n free and, for a diagonal move, not both orthogonal cells occupied (heuristics.cpp:127-132).
+// The pop order among EQUAL costs decides the value only when a straight and a diagonal neighbour tie for that minimum (two
+// straight or two diagonal ones give the same sum).  Such a tie needs two neighbours of n with bit-equal f32 costs whose paths
+// differ in the parity of their straight moves (n's straight and diagonal neighbours lie on different colours of the chessboard):
+// it does not occur on ordinary maps, it is DETECTED here whenever it does, and the goal is then rebuilt by the ordered kernel
+// (pp_wavefront.hip).  Without such a tie (*) has exactly one solution (parents are strictly cheaper, every chain ends at the goal
+// cell), which can be computed in any order.  tests/cpp/model_tile_field.cpp is the CPU statement of what follows, compared with the
+// oracle's sequential restatement in tests/test_tile_field_model.py.
+//
+// Order used here: ONE WAVE PER GOAL, the grid in tiles of 64 x 64 cells, the tile being worked on resident in LDS.
+//   * a tile is solved FROM SCRATCH from its one-cell halo (the neighbouring tiles' border cells as they stand, read back from the
+//     output field) by bucket rounds: round k settles every undiscovered cell that has an allowed neighbour of cost in [k, k+1)
+//     -- every edge costs >= 1 and f32 rounding is monotone, so those neighbours are final, and the new costs land in buckets
+//     k+1 / k+2;
+//   * lane = row of the tile.  Bucket membership, "closed" (occupied or discovered) and the four diagonal-allowed masks are 64-bit
+//     words in registers; the candidate set of a round is a dozen shifts / ANDs / ORs with the two neighbouring rows' words
+//     (DPP wave shifts), and each candidate PULLS its cost: eight LDS reads, two minima, one add.  No open list, no sort, no
+//     atomics, no barrier; global memory is touched at tile load (occupancy bits, halo) and tile store (256-byte lines, each
+//     written whole) only -- the 4-byte scattered stores of the ordered kernel (7x write amplification) are gone;
+//   * tiles are taken in order of the smallest changed halo cost; a solved tile re-queues a neighbour only where one of its
+//     changed border cells could be (or have been) the parent of a neighbour's border cell (cost[parent] <= cost[child] - 1).
+//     When no tile is queued every cell satisfies (*) against its final neighbours.  A run that does not settle within a visit
+//     budget is handed to the ordered kernel like a tie.
+// Measured figures (tile visits per tile, rounds per visit, passes per round): DESIGN.md 4.3b.
+// Algorithmic bytes as for the ordered kernel: 9 B/cell.
+#include "pp_internal.hpp"
+
+#include <cstdlib>
+
+using namespace ppd;
+
+namespace {
+
+constexpr int TT = 64;      // tile edge = lanes of a wave
+constexpr int LS = TT + 2;  // LDS row stride in floats: the tile and its halo
+constexpr int LN = LS * LS; // 4356 floats
+constexpr int LNP = (LN + 3) & ~3;
+constexpr uint32_t kInfBits = 0x7F800000u;
+
+__device__ __forceinline__ void wave_sync()
+{
+	// the lanes of a wave exchange values through LDS: its LDS operations execute in issue order, so only the compiler has to
+	// be kept from moving them across this point
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+/// lane i receives lane i-1's value, lane 0 keeps `first` (DPP wave_shr:1)
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v, uint32_t first) { return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xF, 0xF, false); }
+/// lane i receives lane i+1's value, lane 63 keeps `last` (DPP wave_shl:1)
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v, uint32_t last) { return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130, 0xF, 0xF, false); }
+__device__ __forceinline__ uint64_t from_prev_lane64(uint64_t v, uint64_t first)
+{
+	return (uint64_t)from_prev_lane((uint32_t)v, (uint32_t)first) | ((uint64_t)from_prev_lane((uint32_t)(v >> 32), (uint32_t)(first >> 32)) << 32);
+}
+__device__ __forceinline__ uint64_t from_next_lane64(uint64_t v, uint64_t last)
+{
+	return (uint64_t)from_next_lane((uint32_t)v, (uint32_t)last) | ((uint64_t)from_next_lane((uint32_t)(v >> 32), (uint32_t)(last >> 32)) << 32);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+	const int id = (int)0xFFFFFFFF;
+	uint32_t x = v;
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x111, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x112, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x114, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x118, 0xF, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x142, 0xA, 0xF, false));
+	x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)x, 0x143, 0xC, 0xF, false));
+	return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+/// smallest of non-negative floats (their bit patterns order like the values; +inf = "none")
+__device__ __forceinline__ float wave_min_nonneg(float v) { return __uint_as_float(wave_min_u32(__float_as_uint(v))); }
+
+/// cell (i, j) of a 64 x 64 tile that lane `e % 64` handles in step `e / 64` of a pass over the tile, chosen so that one step
+/// covers whole lines of the output field: tiled field -> consecutive cells of a field tile; row-major -> a row of the tile
+__device__ __forceinline__ void tile_cell(int tiledOut, int e, int& i, int& j)
+{
+	if (tiledOut) {
+		const int ft = e >> (2 * kFieldTileLog2), within = e & ((1 << (2 * kFieldTileLog2)) - 1);
+		constexpr int perRow = TT >> kFieldTileLog2;
+		i = ((ft / perRow) << kFieldTileLog2) + (within >> kFieldTileLog2);
+		j = ((ft % perRow) << kFieldTileLog2) + (within & kFieldTileMask);
+	} else {
+		i = e >> 6;
+		j = e & 63;
+	}
+}
+
+/// occupancy as bits: word (row + 1) * wpr + (col / 64 + 1), bit col % 64; one word of padding on every side, everything
+/// outside the map occupied
+__global__ void __launch_bounds__(256) k_occ_bits(const uint8_t* __restrict__ occ8, int rows, int cols, int wpr, int nWordRows, uint64_t* __restrict__ bits)
+{
+	const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); // one wave per word
+	const int lane = threadIdx.x & 63;
+	if (w >= (int64_t)nWordRows * wpr)
+		return;
+	const int pr = (int)(w / wpr), pw = (int)(w - (int64_t)pr * wpr);
+	const int r = pr - 1, c = (pw - 1) * 64 + lane;
+	bool o = true;
+	if (r >= 0 && r < rows && pw >= 1 && c < cols)
+		o = occ8[(int64_t)r * cols + c] != 0;
+	const uint64_t b = __ballot(o);
+	if (lane == 0)
+		bits[w] = b;
+}
+
+struct TilesArgs {
+	MapView m;
+	int nGoals;
+	const int32_t* goalCells;
+	const double* goalPoses;
+	float* costOut;
+	int tiledOut;
+	int* ctl;        // [0] goal counter, [1] exit counter, [2] number of goals handed to the ordered kernel (fbList)
+	int32_t* fbList; // goals (field slots) this launch could not certify: a tie of (*) or a run that did not settle
+	const double* orderStarts;
+	float* orderKeys;
+	unsigned long long* stats; // optional: {goals, tile visits, rounds, candidate passes, cells, handed over, cycles}
+	int forceFallbackEvery;    // test hook: every n-th goal is handed to the ordered kernel whatever its outcome (0 = never)
+	pph::WavefrontPublish pub;
+};
+
+__global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t smemRaw[];
+	const int lane = threadIdx.x;
+	const MapView& m = A.m;
+	const int rows = m.rows, cols = m.cols;
+	const int TR = (rows + TT - 1) / TT, TC = (cols + TT - 1) / TT, nTiles = TR * TC;
+	float* const L = reinterpret_cast<float*>(smemRaw);                // [LN] the tile being solved, halo included
+	float* const prio = L + LNP;                                       // [nTiles] smallest changed halo cost of a queued tile, +inf = not queued
+	uint8_t* const tstate = reinterpret_cast<uint8_t*>(prio + nTiles); // [nTiles] bit 0: solved at least once
+	const float kInf = __builtin_huge_valf();
+	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
+	const int64_t cells = (int64_t)rows * cols;
+	const int64_t fieldElems = A.tiledOut ? (int64_t)field_tiled_elems(rows, cols) : cells;
+	const uint64_t* const occW = m.occBits;
+	const int wpr = m.occWpr;
+	auto out_index = [&](int r, int c) -> size_t { return A.tiledOut ? field_tiled_index(cols, r, c) : (size_t)r * cols + c; };
+
+	int pendingSlot = -1;
+	bool ringTurn = true;
+	unsigned long long stVisits = 0, stRounds = 0, stPasses = 0, stCells = 0, stGoals = 0, stFb = 0;
+	const unsigned long long t0 = A.stats ? clock64() : 0ull;
+	for (;;) {
+		// ---- hand-out: as k_wavefront's (pp_wavefront.hip), lane 0 in the place of thread 0
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every lane's stores of the previous goal have left the wave
+		int next = -1, st = -1;
+		if (lane == 0) {
+			if (pendingSlot >= 0) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				const unsigned long long t = __hip_atomic_fetch_add(A.pub.readyTail, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(A.pub.ready + (t & A.pub.readyMask), ((t + 1ull) << 32) | (unsigned long long)(uint32_t)pendingSlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			auto take_urgent = [&]() -> int {
+				for (;;) {
+					unsigned long long h = __hip_atomic_load(A.pub.urgentHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const unsigned long long e = __hip_atomic_load(A.pub.urgent + (h & A.pub.urgentMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((uint32_t)(e >> 32) != (uint32_t)(h + 1ull))
+						return -1;
+					if (!__hip_atomic_compare_exchange_strong(A.pub.urgentHead, &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+						continue;
+					const int slot = (int)((uint32_t)e & pph::kSlotMask);
+					int expect = (int)(((uint32_t)e >> pph::kSlotBits) << 1);
+					if (__hip_atomic_compare_exchange_strong(A.pub.claimed + slot, &expect, expect | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+						return slot;
+				}
+			};
+			if (A.pub.urgent && ringTurn)
+				next = take_urgent();
+			while (next < 0) {
+				const int gi = atomicAdd(A.ctl, 1);
+				if (gi >= A.nGoals)
+					break;
+				if (!A.pub.slotList) {
+					next = gi;
+				} else {
+					const uint32_t e = (uint32_t)A.pub.slotList[gi];
+					const int slot = (int)(e & pph::kSlotMask);
+					int expect = (int)((e >> pph::kSlotBits) << 1);
+					if (!A.pub.claimed || __hip_atomic_compare_exchange_strong(A.pub.claimed + slot, &expect, expect | 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+						next = slot;
+				}
+			}
+			ringTurn = !ringTurn;
+			if (next >= 0) {
+				if (A.goalPoses) { // WorldPositionToGridCell(bounded), heuristics.cpp:115
+					double px, py;
+					if (A.pub.claimed) { // (the pose may have been written while this launch was running: see k_wavefront)
+						px = __hip_atomic_load(A.goalPoses + 3 * (size_t)next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						py = __hip_atomic_load(A.goalPoses + 3 * (size_t)next + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					} else {
+						px = A.goalPoses[3 * (size_t)next];
+						py = A.goalPoses[3 * (size_t)next + 1];
+					}
+					int row, col;
+					world_to_cell(m, px, py, row, col);
+					st = inside_map(m, row, col) ? row * m.cols + col : -1;
+				} else {
+					st = A.goalCells[next];
+				}
+			}
+		}
+		const int g = __builtin_amdgcn_readfirstlane(next);
+		const int start = __builtin_amdgcn_readfirstlane(st);
+		pendingSlot = -1;
+		if (g < 0)
+			break;
+		stGoals++;
+		float* const cost = A.costOut + (int64_t)g * fieldElems;
+		const int goalR = start >= 0 ? start / cols : -1, goalC = start >= 0 ? start - goalR * cols : -1;
+
+		for (int t = lane; t < nTiles; t += 64) {
+			prio[t] = kInf;
+			tstate[t] = 0;
+		}
+		wave_sync();
+		if (start >= 0 && lane == 0)
+			prio[(goalR / TT) * TC + goalC / TT] = 0.0f;
+		wave_sync();
+		bool flagged = false; // a tie of (*) somewhere, or the visit budget spent
+		int visits = 0;
+		const int visitBudget = 6 * nTiles + 64;
+
+		for (;;) {
+			// ---- the queued tile whose changed halo is cheapest
+			uint32_t bestBits = kInfBits;
+			int bestT = -1;
+			for (int t = lane; t < nTiles; t += 64) {
+				const uint32_t pb = __float_as_uint(prio[t]);
+				if (pb < bestBits) {
+					bestBits = pb;
+					bestT = t;
+				}
+			}
+			const uint32_t minBits = wave_min_u32(bestBits);
+			if (minBits == kInfBits)
+				break; // nothing queued: the field is settled
+			const uint64_t who = __ballot(bestBits == minBits);
+			const int t = __builtin_amdgcn_readlane(bestT, (int)__builtin_ctzll(who));
+			if (++visits > visitBudget) {
+				flagged = true;
+				break;
+			}
+			const int tr = t / TC, tc = t - tr * TC;
+			const int r0 = tr * TT, c0 = tc * TT;
+			auto solved = [&](int dtr, int dtc) -> bool {
+				const int a = tr + dtr, b = tc + dtc;
+				return a >= 0 && b >= 0 && a < TR && b < TC && (tstate[a * TC + b] & 1);
+			};
+			const bool selfSolved = solved(0, 0);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the halo is read back from lines the previous visits stored
+			// ---- occupancy: this row's word, the bits left and right of it, the rows above and below the tile
+			const size_t wb = (size_t)(r0 + lane + 1) * wpr + (size_t)(tc + 1);
+			const uint64_t occ = occW[wb];
+			const uint32_t occL = (uint32_t)(occW[wb - 1] >> 63), occR = (uint32_t)(occW[wb + 1] & 1ull);
+			const size_t wt = (size_t)r0 * wpr + (size_t)(tc + 1), wbt = (size_t)(r0 + TT + 1) * wpr + (size_t)(tc + 1);
+			const uint64_t tH = occW[wt], bH = occW[wbt];
+			const uint32_t tHL = (uint32_t)(occW[wt - 1] >> 63), tHR = (uint32_t)(occW[wt + 1] & 1ull);
+			const uint32_t bHL = (uint32_t)(occW[wbt - 1] >> 63), bHR = (uint32_t)(occW[wbt + 1] & 1ull);
+			// ---- halo: the neighbouring tiles' border cells as they stand (tiles not solved yet count as +inf), and this tile's own
+			// border as it was after its previous solve
+			float hT = kInf, hB = kInf, hL = kInf, hR = kInf, hC = kInf;
+			float oT = kInf, oB = kInf, oL = kInf, oR = kInf;
+			{
+				const int cj = c0 + lane, ri = r0 + lane;
+				if (cj < cols) {
+					if (solved(-1, 0))
+						hT = cost[out_index(r0 - 1, cj)];
+					if (r0 + TT < rows && solved(1, 0))
+						hB = cost[out_index(r0 + TT, cj)];
+				}
+				if (ri < rows) {
+					if (solved(0, -1))
+						hL = cost[out_index(ri, c0 - 1)];
+					if (c0 + TT < cols && solved(0, 1))
+						hR = cost[out_index(ri, c0 + TT)];
+				}
+				if (lane < 4) {
+					const int dr = lane < 2 ? -1 : 1, dc = (lane & 1) ? 1 : -1;
+					const int rr = dr < 0 ? r0 - 1 : r0 + TT, cc = dc < 0 ? c0 - 1 : c0 + TT;
+					if (rr >= 0 && rr < rows && cc >= 0 && cc < cols && solved(dr, dc))
+						hC = cost[out_index(rr, cc)];
+				}
+				if (selfSolved) {
+					if (cj < cols) {
+						oT = cost[out_index(r0, cj)];
+						if (r0 + TT - 1 < rows)
+							oB = cost[out_index(r0 + TT - 1, cj)];
+					}
+					if (ri < rows) {
+						oL = cost[out_index(ri, c0)];
+						if (c0 + TT - 1 < cols)
+							oR = cost[out_index(ri, c0 + TT - 1)];
+					}
+				}
+			}
+			// ---- LDS: +inf everywhere (undiscovered or occupied), then the halo, then the goal
+			{
+				float4* const L4 = reinterpret_cast<float4*>(L);
+				const float4 inf4 = make_float4(kInf, kInf, kInf, kInf);
+				for (int i = lane; i < LNP / 4; i += 64)
+					L4[i] = inf4;
+			}
+			wave_sync();
+			L[lane + 1] = hT;
+			L[(TT + 1) * LS + lane + 1] = hB;
+			L[(lane + 1) * LS] = hL;
+			L[(lane + 1) * LS + TT + 1] = hR;
+			if (lane < 4)
+				L[(lane < 2 ? 0 : (TT + 1) * LS) + ((lane & 1) ? TT + 1 : 0)] = hC;
+			uint64_t closed = occ, cur = 0ull, nx1 = 0ull, nx2 = 0ull;
+			const bool goalHere = goalR >= r0 && goalR < r0 + TT && goalC >= c0 && goalC < c0 + TT;
+			if (goalHere && lane == goalR - r0) { // the reference pushes the goal cell even when it is occupied (heuristics.cpp:119-121)
+				L[(lane + 1) * LS + (goalC - c0) + 1] = 0.0f;
+				closed |= 1ull << (goalC - c0);
+				cur = 1ull << (goalC - c0);
+			}
+			wave_sync();
+			// buckets of the halo cells: (int)cost, -1 = none
+			const int hbT = hT < kInf ? (int)hT : -1, hbB = hB < kInf ? (int)hB : -1, hbL = hL < kInf ? (int)hL : -1, hbR = hR < kInf ? (int)hR : -1, hbC = hC < kInf ? (int)hC : -1;
+			int kmin;
+			{
+				uint32_t a = 0xFFFFFFFFu;
+				a = min(a, (uint32_t)hbT);
+				a = min(a, (uint32_t)hbB);
+				a = min(a, (uint32_t)hbL);
+				a = min(a, (uint32_t)hbR);
+				a = min(a, (uint32_t)hbC); // (-1 = 0xFFFFFFFF: never the minimum)
+				a = wave_min_u32(a);
+				kmin = goalHere ? 0 : (int)a;
+			}
+			stVisits++;
+			if (kmin >= 0) { // (a tile queued by a border cell that no free halo cell of it sees any more has nothing to start from)
+				// ---- static masks.  Diagonal move into cell (i, j) from (i-1, j-1): blocked iff (i, j-1) and (i-1, j) are both occupied
+				const uint64_t occUp = from_prev_lane64(occ, tH), occDn = from_next_lane64(occ, bH);
+				const uint64_t occWst = (occ << 1) | (uint64_t)occL, occEst = (occ >> 1) | ((uint64_t)occR << 63);
+				const uint64_t aNW = ~(occUp & occWst), aNE = ~(occUp & occEst), aSW = ~(occDn & occWst), aSE = ~(occDn & occEst);
+				int k = kmin;
+				for (;;) {
+					// members of bucket k: `cur` inside the tile, halo cells by their bucket number
+					const uint64_t topM = __ballot(hbT == k), botM = __ballot(hbB == k);
+					const uint32_t cm = (uint32_t)__ballot(hbC == k) & 0xFu; // lanes 0..3 = corners TL, TR, BL, BR
+					const uint32_t lr = (hbL == k ? 1u : 0u) | (hbR == k ? 2u : 0u);
+					const uint32_t lrU = from_prev_lane(lr, cm & 3u), lrD = from_next_lane(lr, (cm >> 2) & 3u);
+					const uint64_t up = from_prev_lane64(cur, topM), dn = from_next_lane64(cur, botM);
+					const uint64_t mW = (cur << 1) | (uint64_t)(lr & 1u), mE = (cur >> 1) | ((uint64_t)(lr >> 1) << 63);
+					const uint64_t mNW = ((up << 1) | (uint64_t)(lrU & 1u)) & aNW, mNE = ((up >> 1) | ((uint64_t)(lrU >> 1) << 63)) & aNE;
+					const uint64_t mSW = ((dn << 1) | (uint64_t)(lrD & 1u)) & aSW, mSE = ((dn >> 1) | ((uint64_t)(lrD >> 1) << 63)) & aSE;
+					uint64_t cand = (mW | mE | up | dn | mNW | mNE | mSW | mSE) & ~closed;
+					stRounds++;
+					const float kNext2 = (float)(k + 2);
+					while (__ballot(cand != 0ull)) {
+						stPasses++;
+						if (cand != 0ull) {
+							const int j = (int)__builtin_ctzll(cand);
+							const uint64_t bit = 1ull << j;
+							cand &= ~bit;
+							const int a = (lane + 1) * LS + j + 1;
+							const float w = L[a - 1], e = L[a + 1], n = L[a - LS], s = L[a + LS];
+							const float nw = L[a - LS - 1], ne = L[a - LS + 1], sw = L[a + LS - 1], se = L[a + LS + 1];
+							const float minS = fminf(fminf(w, e), fminf(n, s));
+							float minD = (aNW & bit) ? nw : kInf;
+							minD = fminf(minD, (aNE & bit) ? ne : kInf);
+							minD = fminf(minD, (aSW & bit) ? sw : kInf);
+							minD = fminf(minD, (aSE & bit) ? se : kInf);
+							flagged |= minS == minD; // a straight and a diagonal neighbour tie for the minimum: the pop order would decide
+							const float v = minS <= minD ? minS + 1.0f : minD + kDiag; // float pathCost = transitionCost + m_cost[cell], heuristics.cpp:134-135
+							L[a] = v;
+							closed |= bit;
+							if (v < kNext2)
+								nx1 |= bit;
+							else
+								nx2 |= bit;
+							stCells++;
+						}
+						wave_sync();
+					}
+					cur = nx1;
+					nx1 = nx2;
+					nx2 = 0ull;
+					if (__ballot(closed != ~0ull) == 0ull)
+						break; // every free cell of the tile has its cost
+					if (__ballot((cur | nx1) != 0ull) != 0ull) {
+						k++;
+					} else { // nothing pending inside: the next bucket that holds a halo cell, if any
+						uint32_t nb = 0xFFFFFFFFu;
+						nb = min(nb, hbT > k ? (uint32_t)hbT : 0xFFFFFFFFu);
+						nb = min(nb, hbB > k ? (uint32_t)hbB : 0xFFFFFFFFu);
+						nb = min(nb, hbL > k ? (uint32_t)hbL : 0xFFFFFFFFu);
+						nb = min(nb, hbR > k ? (uint32_t)hbR : 0xFFFFFFFFu);
+						nb = min(nb, hbC > k ? (uint32_t)hbC : 0xFFFFFFFFu);
+						nb = wave_min_u32(nb);
+						if (nb == 0xFFFFFFFFu)
+							break;
+						k = (int)nb;
+					}
+				}
+			}
+			wave_sync();
+			// ---- which neighbouring tiles must be solved (again): a border cell whose value changed re-queues the tile of a free halo cell
+			// next to it if that cell has no cost yet or one that a parent of the changed cell's (old or new) cost could explain
+			{
+				const float nT = L[LS + lane + 1], nB = L[TT * LS + lane + 1], nL = L[(lane + 1) * LS + 1], nR = L[(lane + 1) * LS + TT];
+				auto sees = [&](float p, float q, uint32_t qOcc) -> bool { return !qOcc && (q == kInf || p < q - 0.99f); };
+				const uint32_t occLU = from_prev_lane(occL, tHL), occLD = from_next_lane(occL, bHL);
+				const uint32_t occRU = from_prev_lane(occR, tHR), occRD = from_next_lane(occR, bHR);
+				float pN = kInf, pS = kInf, pW = kInf, pE = kInf, pNW = kInf, pNE = kInf, pSW = kInf, pSE = kInf;
+				{ // top row, lane = column
+					const bool ch = __float_as_uint(nT) != __float_as_uint(oT);
+					const float p = fminf(nT, oT);
+					const uint32_t o0 = lane == 0 ? tHL : (uint32_t)(tH >> (lane - 1)) & 1u, o1 = (uint32_t)(tH >> lane) & 1u, o2 = lane == 63 ? tHR : (uint32_t)(tH >> (lane + 1)) & 1u;
+					const bool c0_ = ch && sees(p, L[lane], o0), c1_ = ch && sees(p, L[lane + 1], o1), c2_ = ch && sees(p, L[lane + 2], o2);
+					if (c1_ || (lane > 0 && c0_) || (lane < 63 && c2_))
+						pN = p;
+					if (lane == 0 && c0_)
+						pNW = p;
+					if (lane == 63 && c2_)
+						pNE = p;
+				}
+				{ // bottom row
+					const bool ch = __float_as_uint(nB) != __float_as_uint(oB);
+					const float p = fminf(nB, oB);
+					const float* const Lb = L + (TT + 1) * LS;
+					const uint32_t o0 = lane == 0 ? bHL : (uint32_t)(bH >> (lane - 1)) & 1u, o1 = (uint32_t)(bH >> lane) & 1u, o2 = lane == 63 ? bHR : (uint32_t)(bH >> (lane + 1)) & 1u;
+					const bool c0_ = ch && sees(p, Lb[lane], o0), c1_ = ch && sees(p, Lb[lane + 1], o1), c2_ = ch && sees(p, Lb[lane + 2], o2);
+					if (c1_ || (lane > 0 && c0_) || (lane < 63 && c2_))
+						pS = p;
+					if (lane == 0 && c0_)
+						pSW = p;
+					if (lane == 63 && c2_)
+						pSE = p;
+				}
+				{ // left column, lane = row
+					const bool ch = __float_as_uint(nL) != __float_as_uint(oL);
+					const float p = fminf(nL, oL);
+					const bool c0_ = ch && sees(p, L[lane * LS], occLU), c1_ = ch && sees(p, L[(lane + 1) * LS], occL), c2_ = ch && sees(p, L[(lane + 2) * LS], occLD);
+					if (c1_ || (lane > 0 && c0_) || (lane < 63 && c2_))
+						pW = p;
+					if (lane == 0 && c0_)
+						pNW = fminf(pNW, p);
+					if (lane == 63 && c2_)
+						pSW = fminf(pSW, p);
+				}
+				{ // right column
+					const bool ch = __float_as_uint(nR) != __float_as_uint(oR);
+					const float p = fminf(nR, oR);
+					const bool c0_ = ch && sees(p, L[lane * LS + TT + 1], occRU), c1_ = ch && sees(p, L[(lane + 1) * LS + TT + 1], occR), c2_ = ch && sees(p, L[(lane + 2) * LS + TT + 1], occRD);
+					if (c1_ || (lane > 0 && c0_) || (lane < 63 && c2_))
+						pE = p;
+					if (lane == 0 && c0_)
+						pNE = fminf(pNE, p);
+					if (lane == 63 && c2_)
+						pSE = fminf(pSE, p);
+				}
+				const float qN = wave_min_nonneg(pN), qS = wave_min_nonneg(pS), qW = wave_min_nonneg(pW), qE = wave_min_nonneg(pE);
+				const float qNW = wave_min_nonneg(pNW), qNE = wave_min_nonneg(pNE), qSW = wave_min_nonneg(pSW), qSE = wave_min_nonneg(pSE);
+				if (lane == 0) {
+					auto queue = [&](int dtr, int dtc, float p) {
+						const int a = tr + dtr, b = tc + dtc;
+						if (p < kInf && a >= 0 && b >= 0 && a < TR && b < TC && p < prio[a * TC + b])
+							prio[a * TC + b] = p;
+					};
+					prio[t] = kInf;
+					tstate[t] = 1;
+					queue(-1, 0, qN);
+					queue(1, 0, qS);
+					queue(0, -1, qW);
+					queue(0, 1, qE);
+					queue(-1, -1, qNW);
+					queue(-1, 1, qNE);
+					queue(1, -1, qSW);
+					queue(1, 1, qSE);
+				}
+			}
+			// ---- the tile's costs to the output field: whole 256-byte lines (8 x 8-tiled field: one field tile per step; row-major: one row)
+			for (int u = 0; u < TT; u++) {
+				int i, j;
+				tile_cell(A.tiledOut, u * TT + lane, i, j);
+				const int r = r0 + i, c = c0 + j;
+				if (r < rows && c < cols)
+					cost[out_index(r, c)] = L[(i + 1) * LS + j + 1];
+			}
+			wave_sync();
+		}
+		flagged = __ballot(flagged) != 0ull;
+		// ---- +inf for the tiles the wavefront never reached (heuristics.cpp:108-113)
+		if (!flagged) {
+			for (int t = 0; t < nTiles; t++) {
+				if (tstate[t] & 1)
+					continue;
+				const int tr = t / TC, tc = t - tr * TC;
+				for (int u = 0; u < TT; u++) {
+					int i, j;
+					tile_cell(A.tiledOut, u * TT + lane, i, j);
+					const int r = tr * TT + i, c = tc * TT + j;
+					if (r < rows && c < cols)
+						cost[out_index(r, c)] = kInf;
+				}
+			}
+		}
+		if (A.forceFallbackEvery > 0 && (g % A.forceFallbackEvery) == A.forceFallbackEvery - 1)
+			flagged = true;
+		if (flagged) {
+			// not certified: the ordered kernel rebuilds this goal's field from scratch (launch_wavefront queues it behind this launch)
+			stFb++;
+			if (lane == 0)
+				A.fbList[atomicAdd(A.ctl + 2, 1)] = g;
+			continue;
+		}
+		if (A.pub.ready)
+			pendingSlot = g;
+		if (A.orderKeys) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (lane == 0) {
+				int row, col;
+				world_to_cell(m, A.orderStarts[3 * (size_t)g], A.orderStarts[3 * (size_t)g + 1], row, col);
+				float c = kInf;
+				if (inside_map(m, row, col))
+					c = cost[out_index(row, col)];
+				__hip_atomic_store(A.orderKeys + g, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+	if (A.stats && lane == 0) {
+		atomicAdd(A.stats + 0, stGoals);
+		atomicAdd(A.stats + 1, stVisits);
+		atomicAdd(A.stats + 2, stRounds);
+		atomicAdd(A.stats + 3, stPasses);
+		atomicAdd(A.stats + 5, stFb);
+		atomicAdd(A.stats + 6, (unsigned long long)(clock64() - t0));
+	}
+	if (A.stats)
+		atomicAdd(A.stats + 4, stCells); // (counted per lane)
+	// the last wave to leave sets the goal counter back for the stream's next launch (the number of handed-over goals stays: the
+	// ordered kernel's launch behind this one reads it and sets it back in turn)
+	if (lane == 0) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		if (__hip_atomic_fetch_add(A.ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+			__hip_atomic_store(A.ctl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(A.ctl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
+/// the planner's hand-out order (pp_planner.hip): goal indices by decreasing field value at the start pose (+inf = unreachable first);
+/// the ordered kernel does this in its last workgroup, the tile form in one small launch behind its two kernels.  n <= 4096.
+__global__ void __launch_bounds__(512) k_order_by_key(int n, const float* __restrict__ keys, int32_t* __restrict__ orderOut)
+{
+	__shared__ unsigned long long skey[4096];
+	const int tid = threadIdx.x;
+	int P = 1;
+	while (P < n)
+		P <<= 1;
+	for (int i = tid; i < P; i += 512) {
+		unsigned long long v = 0ull;
+		if (i < n)
+			v = ((unsigned long long)(__float_as_uint(keys[i]) + 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+		skey[i] = v;
+	}
+	__syncthreads();
+	for (int kk = 2; kk <= P; kk <<= 1)
+		for (int j = kk >> 1, lj = 31 - __clz(kk >> 1); j > 0; j >>= 1, lj--) {
+			for (int t = tid; t < P / 2; t += 512) {
+				const int i1 = ((t >> lj) << (lj + 1)) | (t & (j - 1)), i2 = i1 + j;
+				const bool desc = (i1 & kk) == 0;
+				const unsigned long long a = skey[i1], b = skey[i2];
+				if ((a < b) == desc) {
+					skey[i1] = b;
+					skey[i2] = a;
+				}
+			}
+			__syncthreads();
+		}
+	for (int i = tid; i < n; i += 512)
+		orderOut[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)skey[i]);
+}
+
+size_t tiles_lds_bytes(int rows, int cols)
+{
+	const size_t nTiles = (size_t)((rows + TT - 1) / TT) * (size_t)((cols + TT - 1) / TT);
+	return ((size_t)LNP * 4 + nTiles * 4 + nTiles + 15) & ~(size_t)15;
+}
+
+} // namespace
+
+namespace pph {
+
+void occ_bits_dims(int rows, int cols, int& wpr, int& nWordRows)
+{
+	wpr = (cols + TT - 1) / TT + 2;
+	nWordRows = (rows + TT - 1) / TT * TT + 2;
+}
+
+hipError_t launch_occ_bits(hipStream_t s, const uint8_t* occ8, int rows, int cols, uint64_t* bits)
+{
+	int wpr, nWordRows;
+	occ_bits_dims(rows, cols, wpr, nWordRows);
+	const int64_t words = (int64_t)wpr * nWordRows;
+	hipLaunchKernelGGL(k_occ_bits, dim3((unsigned)((words + 3) / 4)), dim3(256), 0, s, occ8, rows, cols, wpr, nWordRows, bits);
+	return hipGetLastError();
+}
+
+bool wavefront_tiles_supported(int rows, int cols) { return tiles_lds_bytes(rows, cols) <= 64 * 1024; }
+
+int wavefront_tiles_resident_blocks(int rows, int cols)
+{
+	int perCu = 0, dev = 0;
+	hipDeviceProp_t prop;
+	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+		return 2048;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles, 64, tiles_lds_bytes(rows, cols)) != hipSuccess || perCu < 1)
+		perCu = 1;
+	return perCu * prop.multiProcessorCount;
+}
+
+hipError_t warm_up_wavefront_tiles(hipStream_t s, const MapView& m, int* ctlDev)
+{
+	TilesArgs A {};
+	A.m = m;
+	A.ctl = ctlDev; // nGoals = 0: the wave reads the goal counter, finds nothing and leaves
+	hipLaunchKernelGGL(k_wavefront_tiles, dim3(1), dim3(64), tiles_lds_bytes(m.rows, m.cols), s, A);
+	return hipGetLastError();
+}
+
+hipError_t launch_wavefront_tiles(hipStream_t s, const MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, bool tiledOut, const double* goalPosesDev,
+	const double* orderStartsDev, float* orderKeysDev, const WavefrontPublish& pub)
+{
+	TilesArgs A {};
+	A.m = m;
+	A.nGoals = nGoals;
+	A.goalCells = goalCellsDev;
+	A.goalPoses = goalPosesDev;
+	A.costOut = costDev;
+	A.tiledOut = tiledOut ? 1 : 0;
+	A.ctl = pub.tilesCtl;
+	A.fbList = pub.tilesFallback;
+	A.orderStarts = orderStartsDev;
+	A.orderKeys = orderStartsDev ? orderKeysDev : nullptr;
+	A.stats = pub.tilesStats;
+	A.pub = pub;
+	static const int forceEvery = [] {
+		const char* e = getenv("PP_WF_TILES_FORCE_FALLBACK"); // test hook (tests/test_gpu_parity.py): every n-th goal goes through the hand-over
+		return e ? atoi(e) : 0;
+	}();
+	A.forceFallbackEvery = forceEvery;
+	static int resident = 0;
+	static int residentRows = 0, residentCols = 0;
+	if (!resident || residentRows != m.rows || residentCols != m.cols) {
+		resident = wavefront_tiles_resident_blocks(m.rows, m.cols);
+		residentRows = m.rows;
+		residentCols = m.cols;
+	}
+	int grid = nGoals < resident ? nGoals : resident;
+	if (const char* e = getenv("PP_WF_TILES_GRID")) { // tuning: waves per launch
+		const int g = atoi(e);
+		if (g > 0 && g < grid)
+			grid = g;
+	}
+	hipLaunchKernelGGL(k_wavefront_tiles, dim3(grid), dim3(64), tiles_lds_bytes(m.rows, m.cols), s, A);
+	return hipGetLastError();
+}
+
+hipError_t launch_order_by_key(hipStream_t s, int n, const float* keysDev, int32_t* orderOutDev)
+{
+	hipLaunchKernelGGL(k_order_by_key, dim3(1), dim3(512), 0, s, n, keysDev, orderOutDev);
+	return hipGetLastError();
+}
+
+} // namespace pph

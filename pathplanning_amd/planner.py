@@ -422,6 +422,17 @@ class ObstaclesHeuristic:
         g = _f64(goals_xy, 2)
         check(self.lib.pp_obstacle_heuristic_dev(self.map.h, len(g), ptr(g), _dev_ptr(cost_tensor)))
 
+    TILE_STATS = ("goals", "tile_visits", "rounds", "candidate_passes", "cells", "handed_over", "wave_cycles", "tiles_per_goal")
+
+    def update_dev_tile_stats(self, goals_xy, cost_tensor):
+        """The fields into cost_tensor like update_dev, through the tile form of the wavefront with its work counters:
+        returns (dict of TILE_STATS, launch milliseconds)."""
+        g = _f64(goals_xy, 2)
+        st = np.zeros(8, dtype=np.uint64)
+        ms = C.c_float(0.0)
+        check(self.lib.pp_obstacle_heuristic_tiles_stats(self.map.h, len(g), ptr(g), _dev_ptr(cost_tensor), ptr(st), C.byref(ms)))
+        return dict(zip(self.TILE_STATS, (int(x) for x in st))), float(ms.value)
+
 
 class Tree:
     """Tree::GetNearestNodes (utils/tree.h:73-116): exact kNN, squared L2, ascending."""
