@@ -227,11 +227,13 @@ int pp_nonholo_build(pp_ctx* ctx, const double lower[3], const double upper[3], 
  * when PP_WF_TILES=0 is in the environment.  goal_xy: world positions. */
 int pp_obstacle_heuristic_dev(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev);
 int pp_obstacle_heuristic(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_host);
-/* Diagnostics of the tile form: the same fields into cost_dev ([n_goals][rows*cols]), plus 8 words
+/* Diagnostics of the tile form (a stamped instantiation of its kernel): the same fields into cost_dev ([n_goals][rows*cols]), plus 16 words
  * {goals built, tile visits, bucket rounds, candidate passes, cells settled, goals handed to the ordered kernel,
- * summed wave cycles, tiles per goal} and the launch's duration in ms (HIP events on the context's stream).
+ * summed wave cycles, tiles per goal, then shader-clock sums of a tile visit's phases: loads + LDS set-up, the rounds' masks,
+ * their candidate passes, re-queueing, store issue; 3 spare} and the launch's duration in ms (HIP events on the context's stream).
+ * handed_over_host (optional, [n_goals]): the indices of the goals that were handed over, in no particular order.
  * PP_ERR_INVALID when the tile form is switched off or does not support the map. */
-int pp_obstacle_heuristic_tiles_stats(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev, uint64_t stats_host[8], float* ms_out);
+int pp_obstacle_heuristic_tiles_stats(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev, uint64_t stats_host[16], float* ms_out, int32_t* handed_over_host);
 /* Diagnostics: stamped build of the wavefront kernel; per goal 20 words {init, min, partition, sort, offer, push,
  * tail cycles, rounds, sum of window sizes, rounds with the open list in HBM, fallback rounds, push cycles of fallback rounds,
  * offer sub-phases: store wait, neighbourhood loads, candidate count, whole offer up to the end of insertion,
@@ -345,7 +347,7 @@ int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_checke
 /* ---- streaming form of HybridAStar::SearchPath's search stage (algo/hybrid_a_star.cpp:237-257) ------------------------------
  * One pipeline per GPU: `capacity` queries in flight (a field slot each: the obstacle-heuristic field of its goal, start / goal /
  * seed, path and Reeds-Shepp log), ObstaclesHeuristic::Update by the wavefront kernel, which hands every finished field to ONE
- * persistent search grid of `search_rows` rows (0 = 2560) through a device-side queue; a row takes the next ready query as soon as
+ * persistent search grid of `search_rows` rows (0 = 3072) through a device-side queue; a row takes the next ready query as soon as
  * its own ends, slots are recycled as results are polled.  No batch boundary: a query that exhausts the lattice (~1 s) holds one
  * row, not a batch's 17 GB of fields.  Results per query are exactly those of pp_planner_search_batch (same kernels' device code).
  * log_expansions != 0 keeps the expansion log per slot (parity tests; 4 B x max_nodes_per_query per slot).

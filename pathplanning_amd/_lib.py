@@ -149,7 +149,7 @@ def load():
     L.pp_obstacle_heuristic_dev.argtypes = [vp, C.c_int32, vp, vp]
     L.pp_obstacle_heuristic_workspace_bytes.argtypes = [vp]
     L.pp_obstacle_heuristic_profile.argtypes = [vp, C.c_int32, vp, vp]
-    L.pp_obstacle_heuristic_tiles_stats.argtypes = [vp, C.c_int32, vp, vp, vp, vp]
+    L.pp_obstacle_heuristic_tiles_stats.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
     L.pp_planner_create.argtypes = [vp, C.POINTER(HybridParams), C.c_int32, C.c_int32, C.POINTER(vp)]
     L.pp_planner_search_rows.argtypes = [vp]
     L.pp_planner_debug_nodes.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp]

@@ -754,7 +754,7 @@ int pp_obstacle_heuristic_dev(pp_map* map, int32_t n_goals, const double* goal_x
 	return PP_OK;
 }
 
-int pp_obstacle_heuristic_tiles_stats(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev, uint64_t stats_host[8], float* ms_out)
+int pp_obstacle_heuristic_tiles_stats(pp_map* map, int32_t n_goals, const double* goal_xy_host, float* cost_dev, uint64_t stats_host[16], float* ms_out, int32_t* handed_over_host)
 {
 	if (check_map(map, false) || !map->occ8 || n_goals <= 0 || !goal_xy_host || !cost_dev || !stats_host) {
 		set_error("invalid arguments");
@@ -775,10 +775,10 @@ int pp_obstacle_heuristic_tiles_stats(pp_map* map, int32_t n_goals, const double
 	PP_HIP_TRY(dc.alloc((size_t)n_goals * 4));
 	PP_HIP_TRY(derr.alloc(8));
 	PP_HIP_TRY(dtiles.alloc(64 + (size_t)n_goals * 4));
-	PP_HIP_TRY(dstats.alloc(64));
+	PP_HIP_TRY(dstats.alloc(128));
 	PP_HIP_TRY(hipMemsetAsync(derr.p, 0, 8, s));
 	PP_HIP_TRY(hipMemsetAsync(dtiles.p, 0, 64, s));
-	PP_HIP_TRY(hipMemsetAsync(dstats.p, 0, 64, s));
+	PP_HIP_TRY(hipMemsetAsync(dstats.p, 0, 128, s));
 	PP_HIP_TRY(hipMemcpyAsync(dc.p, cells.data(), (size_t)n_goals * 4, hipMemcpyHostToDevice, s));
 	WavefrontPublish pub;
 	pub.tilesCtl = dtiles.as<int>();
@@ -790,7 +790,9 @@ int pp_obstacle_heuristic_tiles_stats(pp_map* map, int32_t n_goals, const double
 	PP_HIP_TRY(hipEventRecord(map->ctx->ev1, s));
 	int32_t err = 0;
 	PP_HIP_TRY(hipMemcpyAsync(&err, derr.p, 4, hipMemcpyDeviceToHost, s));
-	PP_HIP_TRY(hipMemcpyAsync(stats_host, dstats.p, 64, hipMemcpyDeviceToHost, s));
+	PP_HIP_TRY(hipMemcpyAsync(stats_host, dstats.p, 128, hipMemcpyDeviceToHost, s));
+	if (handed_over_host) // (the list outlives the launches: only the count is set back)
+		PP_HIP_TRY(hipMemcpyAsync(handed_over_host, dtiles.as<int32_t>() + 16, (size_t)n_goals * 4, hipMemcpyDeviceToHost, s));
 	PP_HIP_TRY(hipStreamSynchronize(s));
 	stats_host[7] = (uint64_t)((map->desc.rows + 63) / 64) * (uint64_t)((map->desc.cols + 63) / 64);
 	if (ms_out)

@@ -250,7 +250,7 @@ int pipe_launch_search(pp_pipeline* P)
 	hipStream_t s = P->searchStream[P->nextSearch];
 	P->nextSearch = (P->nextSearch + 1) % kPipeSearchStreams;
 	PP_HIP_TRY(hipStreamWaitEvent(s, P->evCtl, 0));
-	constexpr int kWg = PP_ROWS_WAVES_PER_WG;
+	constexpr int kWg = 1; // (single-wave workgroups: see k_hybrid_search_rows)
 	pl->args.rowsWaves = P->waves;
 	pl->args.m = pl->map->view(); // validator tunables may have changed
 	const pp_pipeline::Timed tm = timed_take(P, s, 1, 0);
@@ -277,7 +277,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	auto* P = new pp_pipeline();
 	P->capacity = capacity;
 	if (search_rows == 0)
-		search_rows = 2560; // measured optimum on MI355X (profiles/r03_pipeline_sweep.txt): beyond it the wavefront kernel, which needs the other CUs' registers, becomes the bottleneck
+		search_rows = 3072; // measured optimum on MI355X with the tile form of the wavefront (profiles/r04_pipeline_sweeps.txt; 2560 with the ordered kernel, round 3)
 	if (int rc = create_planner(map, params, capacity, max_nodes_per_query, search_rows, log_expansions ? PlannerUse::PipelineLogged : PlannerUse::Pipeline, &P->pl)) {
 		delete P;
 		return rc;
@@ -310,6 +310,27 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		if (x >= 1 && x <= kPipeWavefrontStreams)
 			P->nWf = (int)x;
 	}
+	// Experiment switch PP_PIPE_WF_CUS=n: the wavefront streams run on the first n compute units only and the search streams on the others
+	// (hipExtStreamCreateWithCUMask): no stage can take the other's LDS or registers.  0 / unset = no masks.
+	int wfCus = 0, totalCus = 0;
+	{
+		int dev = 0;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+			totalCus = prop.multiProcessorCount;
+		if (const char* v = getenv("PP_PIPE_WF_CUS")) {
+			const long x = strtol(v, nullptr, 10);
+			if (x > 0 && x < totalCus && totalCus <= 512)
+				wfCus = (int)x;
+		}
+	}
+	auto masked_stream = [&](hipStream_t* out, bool forWavefront) -> hipError_t {
+		uint32_t mask[16] = {};
+		for (int c = 0; c < totalCus; c++)
+			if ((c < wfCus) == forWavefront)
+				mask[c >> 5] |= 1u << (c & 31);
+		return hipExtStreamCreateWithCUMask(out, (uint32_t)((totalCus + 31) / 32), mask);
+	};
 	for (int i = 0; i < P->nWf && e == hipSuccess; i++) {
 		e = hipMalloc(&P->wfWorkspace[i], (size_t)pl->wfBytesPerSlot * pl->wfSlots);
 		if (e == hipSuccess)
@@ -319,7 +340,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		if (e == hipSuccess)
 			e = hipMalloc((void**)&P->wfFallback[i], (size_t)capacity * 4);
 		if (e == hipSuccess)
-			e = hipStreamCreateWithFlags(&P->wfStream[i], hipStreamNonBlocking);
+			e = wfCus ? masked_stream(&P->wfStream[i], true) : hipStreamCreateWithFlags(&P->wfStream[i], hipStreamNonBlocking);
 	}
 	// The wavefront workgroups of a launch in flight stay until its list AND the urgent ring are empty, and launches queue: room on the chip
 	// frees rarely and in bursts.  When it does, the waves that top up the search grid and the scatter kernel of a new submission should get
@@ -331,7 +352,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	if (getenv("PP_PIPE_FLAT_PRIORITY"))
 		prioHigh = prioLow = 0;
 	for (int i = 0; i < kPipeSearchStreams && e == hipSuccess; i++)
-		e = hipStreamCreateWithPriority(&P->searchStream[i], hipStreamNonBlocking, prioHigh);
+		e = wfCus ? masked_stream(&P->searchStream[i], false) : hipStreamCreateWithPriority(&P->searchStream[i], hipStreamNonBlocking, prioHigh);
 	if (e == hipSuccess)
 		e = hipStreamCreateWithPriority(&P->ctlStream, hipStreamNonBlocking, prioHigh);
 	if (e == hipSuccess)

@@ -65,7 +65,11 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 	// that they land on ONE compute unit: with the longest-first hand-out order the first waves hold the longest queries,
 	// and the long-lived waves of a batch then sit on few CUs instead of one CU each (every CU that hosts a search wave
 	// has room for only one of the two wavefront workgroups it could run).
-	constexpr int kW = PP_ROWS_WAVES_PER_WG;
+	// waves per workgroup: the batch form launches four together so that a batch's long-lived waves share CUs; the pipeline form launches
+	// single waves -- its grid is topped up at every submission, and a topped-up workgroup in which one wave found its index free and
+	// three found theirs owned holds four waves' LDS and registers for one wave's work (measured: with 4096 rows and more, a third of the
+	// grid's rows never became resident again)
+	constexpr int kW = kPiped ? 1 : PP_ROWS_WAVES_PER_WG;
 	const int lane = threadIdx.x & 63;
 	const int waveIdx = (int)blockIdx.x * kW + (int)(threadIdx.x >> 6);
 	if (waveIdx >= A.rowsWaves)

@@ -32,16 +32,28 @@
 #include "pp_internal.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 using namespace ppd;
 
 namespace {
 
-constexpr int TT = 64;      // tile edge = lanes of a wave
-constexpr int LS = TT + 2;  // LDS row stride in floats: the tile and its halo
-constexpr int LN = LS * LS; // 4356 floats
-constexpr int LNP = (LN + 3) & ~3;
+constexpr int TT = 64; // rows of a tile = lanes of a wave
+// columns of a tile: TW = 64 (one 64-bit mask word per row) or 32 (half the LDS per wave: twice the waves per CU)
+template <int TW>
+struct TileShape {
+	static constexpr int LS = TW + 2;         // LDS row stride in floats: the tile and its halo
+	static constexpr int LN = (TT + 2) * LS;  // floats
+	static constexpr int LNP = (LN + 3) & ~3;
+	typedef typename std::conditional<TW == 64, uint64_t, uint32_t>::type Mask;
+};
 constexpr uint32_t kInfBits = 0x7F800000u;
+#ifndef PP_WF_TILES_PRIO_DEFAULT
+#define PP_WF_TILES_PRIO_DEFAULT 1 // as the search rows' (PP_ROWS_PRIO): measured 22.9-23.6 k plans/s against 19.3-22.4 k at 0 and 19.4 k at 2 (gpurun_out/r4_sweep_prio.txt)
+#endif
+#ifndef PP_WF_TILE_WIDTH_DEFAULT
+#define PP_WF_TILE_WIDTH_DEFAULT 64
+#endif
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -62,6 +74,10 @@ __device__ __forceinline__ uint64_t from_next_lane64(uint64_t v, uint64_t last)
 {
 	return (uint64_t)from_next_lane((uint32_t)v, (uint32_t)last) | ((uint64_t)from_next_lane((uint32_t)(v >> 32), (uint32_t)(last >> 32)) << 32);
 }
+__device__ __forceinline__ uint32_t mask_from_prev(uint32_t v, uint32_t first) { return from_prev_lane(v, first); }
+__device__ __forceinline__ uint32_t mask_from_next(uint32_t v, uint32_t last) { return from_next_lane(v, last); }
+__device__ __forceinline__ uint64_t mask_from_prev(uint64_t v, uint64_t first) { return from_prev_lane64(v, first); }
+__device__ __forceinline__ uint64_t mask_from_next(uint64_t v, uint64_t last) { return from_next_lane64(v, last); }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
 	const int id = (int)0xFFFFFFFF;
@@ -77,18 +93,19 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 /// smallest of non-negative floats (their bit patterns order like the values; +inf = "none")
 __device__ __forceinline__ float wave_min_nonneg(float v) { return __uint_as_float(wave_min_u32(__float_as_uint(v))); }
 
-/// cell (i, j) of a 64 x 64 tile that lane `e % 64` handles in step `e / 64` of a pass over the tile, chosen so that one step
+/// cell (i, j) of a 64 x TW tile that lane `e % 64` handles in step `e / 64` of a pass over the tile, chosen so that one step
 /// covers whole lines of the output field: tiled field -> consecutive cells of a field tile; row-major -> a row of the tile
+template <int TW>
 __device__ __forceinline__ void tile_cell(int tiledOut, int e, int& i, int& j)
 {
 	if (tiledOut) {
 		const int ft = e >> (2 * kFieldTileLog2), within = e & ((1 << (2 * kFieldTileLog2)) - 1);
-		constexpr int perRow = TT >> kFieldTileLog2;
+		constexpr int perRow = TW >> kFieldTileLog2;
 		i = ((ft / perRow) << kFieldTileLog2) + (within >> kFieldTileLog2);
 		j = ((ft % perRow) << kFieldTileLog2) + (within & kFieldTileMask);
 	} else {
-		i = e >> 6;
-		j = e & 63;
+		i = e / TW;
+		j = e % TW;
 	}
 }
 
@@ -123,17 +140,45 @@ struct TilesArgs {
 	float* orderKeys;
 	unsigned long long* stats; // optional: {goals, tile visits, rounds, candidate passes, cells, handed over, cycles}
 	int forceFallbackEvery;    // test hook: every n-th goal is handed to the ordered kernel whatever its outcome (0 = never)
+	int ldsPerWave;            // bytes of LDS per wave of a workgroup
+	int prio;                  // s_setprio level of the waves (0..3)
 	pph::WavefrontPublish pub;
 };
 
-__global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
+// A workgroup is a PACK of independent waves (no barrier, no shared data: each wave has its own slice of the workgroup's LDS and its own
+// goals).  Waves are packed so that the workgroup's LDS exceeds half a CU's: at most one pack per CU, which always leaves room for a
+// workgroup of the search grid (57 KB, 256 VGPRs per wave) next to it -- single-wave workgroups fill every CU's LDS eight at a time and
+// keep the persistent search grid's workgroups from becoming resident (measured: 4096 search rows, 1000 of them busy).
+template <int TW, bool kProf>
+__global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 {
-	extern __shared__ __attribute__((aligned(16))) uint32_t smemRaw[];
-	const int lane = threadIdx.x;
+	// kProf (diagnostic instantiation, pp_obstacle_heuristic_tiles_stats): shader-clock sums per phase of a tile visit
+	unsigned long long ph[5] = { 0, 0, 0, 0, 0 }, tl = 0;
+#define TILE_STAMP(i)                                        \
+	if (kProf) {                                             \
+		const unsigned long long now_ = __builtin_readcyclecounter(); \
+		ph[i] += now_ - tl;                                  \
+		tl = now_;                                           \
+	}
+	typedef typename TileShape<TW>::Mask Mask;
+	constexpr int LS = TileShape<TW>::LS, LNP = TileShape<TW>::LNP;
+	constexpr Mask kAll = (Mask)~(Mask)0;
+	extern __shared__ __attribute__((aligned(16))) uint32_t smemAll[];
+	const int lane = threadIdx.x & 63;
+	uint32_t* const smemRaw = smemAll + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (size_t)(A.ldsPerWave >> 2);
+	// issue priority next to the search grid's waves (which run at PP_ROWS_PRIO = 1): a wave here is a chain of short dependent steps that
+	// issues an instruction every ~9 cycles; ahead of the search waves it costs them few slots, behind them it waits for theirs
+	if (A.prio == 1)
+		__builtin_amdgcn_s_setprio(1);
+	else if (A.prio == 2)
+		__builtin_amdgcn_s_setprio(2);
+	else if (A.prio == 3)
+		__builtin_amdgcn_s_setprio(3);
 	const MapView& m = A.m;
 	const int rows = m.rows, cols = m.cols;
-	const int TR = (rows + TT - 1) / TT, TC = (cols + TT - 1) / TT, nTiles = TR * TC;
+	const int TR = (rows + TT - 1) / TT, TC = (cols + TW - 1) / TW, nTiles = TR * TC;
 	float* const L = reinterpret_cast<float*>(smemRaw);                // [LN] the tile being solved, halo included
+	const uint32_t* const Lu = smemRaw;
 	float* const prio = L + LNP;                                       // [nTiles] smallest changed halo cost of a queued tile, +inf = not queued
 	uint8_t* const tstate = reinterpret_cast<uint8_t*>(prio + nTiles); // [nTiles] bit 0: solved at least once
 	const float kInf = __builtin_huge_valf();
@@ -147,7 +192,7 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 	int pendingSlot = -1;
 	bool ringTurn = true;
 	unsigned long long stVisits = 0, stRounds = 0, stPasses = 0, stCells = 0, stGoals = 0, stFb = 0;
-	const unsigned long long t0 = A.stats ? clock64() : 0ull;
+	const unsigned long long t0 = A.stats ? __builtin_readcyclecounter() : 0ull;
 	for (;;) {
 		// ---- hand-out: as k_wavefront's (pp_wavefront.hip), lane 0 in the place of thread 0
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every lane's stores of the previous goal have left the wave
@@ -223,7 +268,7 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 		}
 		wave_sync();
 		if (start >= 0 && lane == 0)
-			prio[(goalR / TT) * TC + goalC / TT] = 0.0f;
+			prio[(goalR / TT) * TC + goalC / TW] = 0.0f;
 		wave_sync();
 		bool flagged = false; // a tie of (*) somewhere, or the visit budget spent
 		int visits = 0;
@@ -249,29 +294,37 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 				flagged = true;
 				break;
 			}
+			if (kProf)
+				tl = __builtin_readcyclecounter();
 			const int tr = t / TC, tc = t - tr * TC;
-			const int r0 = tr * TT, c0 = tc * TT;
+			const int r0 = tr * TT, c0 = tc * TW;
 			auto solved = [&](int dtr, int dtc) -> bool {
 				const int a = tr + dtr, b = tc + dtc;
 				return a >= 0 && b >= 0 && a < TR && b < TC && (tstate[a * TC + b] & 1);
 			};
 			const bool selfSolved = solved(0, 0);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the halo is read back from lines the previous visits stored
-			// ---- occupancy: this row's word, the bits left and right of it, the rows above and below the tile
-			const size_t wb = (size_t)(r0 + lane + 1) * wpr + (size_t)(tc + 1);
-			const uint64_t occ = occW[wb];
-			const uint32_t occL = (uint32_t)(occW[wb - 1] >> 63), occR = (uint32_t)(occW[wb + 1] & 1ull);
-			const size_t wt = (size_t)r0 * wpr + (size_t)(tc + 1), wbt = (size_t)(r0 + TT + 1) * wpr + (size_t)(tc + 1);
-			const uint64_t tH = occW[wt], bH = occW[wbt];
-			const uint32_t tHL = (uint32_t)(occW[wt - 1] >> 63), tHR = (uint32_t)(occW[wt + 1] & 1ull);
-			const uint32_t bHL = (uint32_t)(occW[wbt - 1] >> 63), bHR = (uint32_t)(occW[wbt + 1] & 1ull);
+			// ---- occupancy: this row's bits, the bits left and right of them, the rows above and below the tile.  A tile's TW columns
+			// lie inside one 64-bit word of the padded bit grid (TW divides 64, tiles are aligned)
+			auto occ_bits = [&](int prow, int cFirst) -> Mask { // TW bits from column cFirst of padded row prow
+				const uint64_t w = occW[(size_t)prow * wpr + (size_t)((cFirst >> 6) + 1)];
+				return (Mask)(w >> (cFirst & 63));
+			};
+			auto occ_bit = [&](int prow, int c) -> uint32_t { // (c = -1 and c = cols.. fall into the padding words: occupied)
+				return (uint32_t)(occW[(size_t)prow * wpr + (size_t)((c >> 6) + 1)] >> (c & 63)) & 1u;
+			};
+			const Mask occ = occ_bits(r0 + lane + 1, c0);
+			const uint32_t occL = occ_bit(r0 + lane + 1, c0 - 1), occR = occ_bit(r0 + lane + 1, c0 + TW);
+			const Mask tH = occ_bits(r0, c0), bH = occ_bits(r0 + TT + 1, c0);
+			const uint32_t tHL = occ_bit(r0, c0 - 1), tHR = occ_bit(r0, c0 + TW);
+			const uint32_t bHL = occ_bit(r0 + TT + 1, c0 - 1), bHR = occ_bit(r0 + TT + 1, c0 + TW);
 			// ---- halo: the neighbouring tiles' border cells as they stand (tiles not solved yet count as +inf), and this tile's own
 			// border as it was after its previous solve
 			float hT = kInf, hB = kInf, hL = kInf, hR = kInf, hC = kInf;
 			float oT = kInf, oB = kInf, oL = kInf, oR = kInf;
 			{
 				const int cj = c0 + lane, ri = r0 + lane;
-				if (cj < cols) {
+				if (lane < TW && cj < cols) {
 					if (solved(-1, 0))
 						hT = cost[out_index(r0 - 1, cj)];
 					if (r0 + TT < rows && solved(1, 0))
@@ -280,25 +333,25 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 				if (ri < rows) {
 					if (solved(0, -1))
 						hL = cost[out_index(ri, c0 - 1)];
-					if (c0 + TT < cols && solved(0, 1))
-						hR = cost[out_index(ri, c0 + TT)];
+					if (c0 + TW < cols && solved(0, 1))
+						hR = cost[out_index(ri, c0 + TW)];
 				}
 				if (lane < 4) {
 					const int dr = lane < 2 ? -1 : 1, dc = (lane & 1) ? 1 : -1;
-					const int rr = dr < 0 ? r0 - 1 : r0 + TT, cc = dc < 0 ? c0 - 1 : c0 + TT;
+					const int rr = dr < 0 ? r0 - 1 : r0 + TT, cc = dc < 0 ? c0 - 1 : c0 + TW;
 					if (rr >= 0 && rr < rows && cc >= 0 && cc < cols && solved(dr, dc))
 						hC = cost[out_index(rr, cc)];
 				}
 				if (selfSolved) {
-					if (cj < cols) {
+					if (lane < TW && cj < cols) {
 						oT = cost[out_index(r0, cj)];
 						if (r0 + TT - 1 < rows)
 							oB = cost[out_index(r0 + TT - 1, cj)];
 					}
 					if (ri < rows) {
 						oL = cost[out_index(ri, c0)];
-						if (c0 + TT - 1 < cols)
-							oR = cost[out_index(ri, c0 + TT - 1)];
+						if (c0 + TW - 1 < cols)
+							oR = cost[out_index(ri, c0 + TW - 1)];
 					}
 				}
 			}
@@ -310,18 +363,20 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 					L4[i] = inf4;
 			}
 			wave_sync();
-			L[lane + 1] = hT;
-			L[(TT + 1) * LS + lane + 1] = hB;
+			if (lane < TW) {
+				L[lane + 1] = hT;
+				L[(TT + 1) * LS + lane + 1] = hB;
+			}
 			L[(lane + 1) * LS] = hL;
-			L[(lane + 1) * LS + TT + 1] = hR;
+			L[(lane + 1) * LS + TW + 1] = hR;
 			if (lane < 4)
-				L[(lane < 2 ? 0 : (TT + 1) * LS) + ((lane & 1) ? TT + 1 : 0)] = hC;
-			uint64_t closed = occ, cur = 0ull, nx1 = 0ull, nx2 = 0ull;
-			const bool goalHere = goalR >= r0 && goalR < r0 + TT && goalC >= c0 && goalC < c0 + TT;
+				L[(lane < 2 ? 0 : (TT + 1) * LS) + ((lane & 1) ? TW + 1 : 0)] = hC;
+			Mask closed = occ, cur = 0, nx1 = 0, nx2 = 0;
+			const bool goalHere = goalR >= r0 && goalR < r0 + TT && goalC >= c0 && goalC < c0 + TW;
 			if (goalHere && lane == goalR - r0) { // the reference pushes the goal cell even when it is occupied (heuristics.cpp:119-121)
 				L[(lane + 1) * LS + (goalC - c0) + 1] = 0.0f;
-				closed |= 1ull << (goalC - c0);
-				cur = 1ull << (goalC - c0);
+				closed |= (Mask)1 << (goalC - c0);
+				cur = (Mask)1 << (goalC - c0);
 			}
 			wave_sync();
 			// buckets of the halo cells: (int)cost, -1 = none
@@ -338,41 +393,45 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 				kmin = goalHere ? 0 : (int)a;
 			}
 			stVisits++;
+			TILE_STAMP(0) // loads, LDS set-up
 			if (kmin >= 0) { // (a tile queued by a border cell that no free halo cell of it sees any more has nothing to start from)
 				// ---- static masks.  Diagonal move into cell (i, j) from (i-1, j-1): blocked iff (i, j-1) and (i-1, j) are both occupied
-				const uint64_t occUp = from_prev_lane64(occ, tH), occDn = from_next_lane64(occ, bH);
-				const uint64_t occWst = (occ << 1) | (uint64_t)occL, occEst = (occ >> 1) | ((uint64_t)occR << 63);
-				const uint64_t aNW = ~(occUp & occWst), aNE = ~(occUp & occEst), aSW = ~(occDn & occWst), aSE = ~(occDn & occEst);
+				const Mask occUp = mask_from_prev(occ, tH), occDn = mask_from_next(occ, bH);
+				const Mask occWst = (Mask)(occ << 1) | (Mask)occL, occEst = (Mask)(occ >> 1) | ((Mask)occR << (TW - 1));
+				const Mask aNW = ~(occUp & occWst), aNE = ~(occUp & occEst), aSW = ~(occDn & occWst), aSE = ~(occDn & occEst);
 				int k = kmin;
 				for (;;) {
 					// members of bucket k: `cur` inside the tile, halo cells by their bucket number
-					const uint64_t topM = __ballot(hbT == k), botM = __ballot(hbB == k);
+					const Mask topM = (Mask)__ballot(hbT == k), botM = (Mask)__ballot(hbB == k);
 					const uint32_t cm = (uint32_t)__ballot(hbC == k) & 0xFu; // lanes 0..3 = corners TL, TR, BL, BR
 					const uint32_t lr = (hbL == k ? 1u : 0u) | (hbR == k ? 2u : 0u);
 					const uint32_t lrU = from_prev_lane(lr, cm & 3u), lrD = from_next_lane(lr, (cm >> 2) & 3u);
-					const uint64_t up = from_prev_lane64(cur, topM), dn = from_next_lane64(cur, botM);
-					const uint64_t mW = (cur << 1) | (uint64_t)(lr & 1u), mE = (cur >> 1) | ((uint64_t)(lr >> 1) << 63);
-					const uint64_t mNW = ((up << 1) | (uint64_t)(lrU & 1u)) & aNW, mNE = ((up >> 1) | ((uint64_t)(lrU >> 1) << 63)) & aNE;
-					const uint64_t mSW = ((dn << 1) | (uint64_t)(lrD & 1u)) & aSW, mSE = ((dn >> 1) | ((uint64_t)(lrD >> 1) << 63)) & aSE;
-					uint64_t cand = (mW | mE | up | dn | mNW | mNE | mSW | mSE) & ~closed;
+					const Mask up = mask_from_prev(cur, topM), dn = mask_from_next(cur, botM);
+					const Mask mW = (Mask)(cur << 1) | (Mask)(lr & 1u), mE = (Mask)(cur >> 1) | ((Mask)(lr >> 1) << (TW - 1));
+					const Mask mNW = ((Mask)(up << 1) | (Mask)(lrU & 1u)) & aNW, mNE = ((Mask)(up >> 1) | ((Mask)(lrU >> 1) << (TW - 1))) & aNE;
+					const Mask mSW = ((Mask)(dn << 1) | (Mask)(lrD & 1u)) & aSW, mSE = ((Mask)(dn >> 1) | ((Mask)(lrD >> 1) << (TW - 1))) & aSE;
+					Mask cand = (mW | mE | up | dn | mNW | mNE | mSW | mSE) & (Mask)~closed;
 					stRounds++;
+					TILE_STAMP(1) // a round's masks
 					const float kNext2 = (float)(k + 2);
-					while (__ballot(cand != 0ull)) {
+					while (__ballot(cand != 0)) {
 						stPasses++;
-						if (cand != 0ull) {
-							const int j = (int)__builtin_ctzll(cand);
-							const uint64_t bit = 1ull << j;
-							cand &= ~bit;
+						if (cand != 0) {
+							const int j = (int)__builtin_ctzll((uint64_t)cand);
+							const Mask bit = (Mask)1 << j;
+							cand &= (Mask)~bit;
 							const int a = (lane + 1) * LS + j + 1;
-							const float w = L[a - 1], e = L[a + 1], n = L[a - LS], s = L[a + LS];
-							const float nw = L[a - LS - 1], ne = L[a - LS + 1], sw = L[a + LS - 1], se = L[a + LS + 1];
-							const float minS = fminf(fminf(w, e), fminf(n, s));
-							float minD = (aNW & bit) ? nw : kInf;
-							minD = fminf(minD, (aNE & bit) ? ne : kInf);
-							minD = fminf(minD, (aSW & bit) ? sw : kInf);
-							minD = fminf(minD, (aSE & bit) ? se : kInf);
+							// costs are non-negative floats (+inf = none): their bit patterns order like the values, so the minima are integer
+							// minima (v_min3_u32; a float minimum first quiets its operands: six more instructions per candidate)
+							const uint32_t w = Lu[a - 1], e = Lu[a + 1], n = Lu[a - LS], s = Lu[a + LS];
+							const uint32_t nw = Lu[a - LS - 1], ne = Lu[a - LS + 1], sw = Lu[a + LS - 1], se = Lu[a + LS + 1];
+							const uint32_t minS = min(min(w, e), min(n, s));
+							uint32_t minD = (aNW & bit) ? nw : kInfBits;
+							minD = min(minD, (aNE & bit) ? ne : kInfBits);
+							minD = min(minD, (aSW & bit) ? sw : kInfBits);
+							minD = min(minD, (aSE & bit) ? se : kInfBits);
 							flagged |= minS == minD; // a straight and a diagonal neighbour tie for the minimum: the pop order would decide
-							const float v = minS <= minD ? minS + 1.0f : minD + kDiag; // float pathCost = transitionCost + m_cost[cell], heuristics.cpp:134-135
+							const float v = minS <= minD ? __uint_as_float(minS) + 1.0f : __uint_as_float(minD) + kDiag; // float pathCost = transitionCost + m_cost[cell], heuristics.cpp:134-135
 							L[a] = v;
 							closed |= bit;
 							if (v < kNext2)
@@ -383,12 +442,13 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 						}
 						wave_sync();
 					}
+					TILE_STAMP(2) // its candidate passes
 					cur = nx1;
 					nx1 = nx2;
-					nx2 = 0ull;
-					if (__ballot(closed != ~0ull) == 0ull)
+					nx2 = 0;
+					if (__ballot(closed != kAll) == 0ull)
 						break; // every free cell of the tile has its cost
-					if (__ballot((cur | nx1) != 0ull) != 0ull) {
+					if (__ballot((cur | nx1) != 0) != 0ull) {
 						k++;
 					} else { // nothing pending inside: the next bucket that holds a halo cell, if any
 						uint32_t nb = 0xFFFFFFFFu;
@@ -408,34 +468,35 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 			// ---- which neighbouring tiles must be solved (again): a border cell whose value changed re-queues the tile of a free halo cell
 			// next to it if that cell has no cost yet or one that a parent of the changed cell's (old or new) cost could explain
 			{
-				const float nT = L[LS + lane + 1], nB = L[TT * LS + lane + 1], nL = L[(lane + 1) * LS + 1], nR = L[(lane + 1) * LS + TT];
+				const int lc = lane < TW ? lane : 0; // (top / bottom rows: lanes beyond the tile's columns idle)
+				const float nT = lane < TW ? L[LS + lc + 1] : kInf, nB = lane < TW ? L[TT * LS + lc + 1] : kInf, nL = L[(lane + 1) * LS + 1], nR = L[(lane + 1) * LS + TW];
 				auto sees = [&](float p, float q, uint32_t qOcc) -> bool { return !qOcc && (q == kInf || p < q - 0.99f); };
 				const uint32_t occLU = from_prev_lane(occL, tHL), occLD = from_next_lane(occL, bHL);
 				const uint32_t occRU = from_prev_lane(occR, tHR), occRD = from_next_lane(occR, bHR);
 				float pN = kInf, pS = kInf, pW = kInf, pE = kInf, pNW = kInf, pNE = kInf, pSW = kInf, pSE = kInf;
 				{ // top row, lane = column
-					const bool ch = __float_as_uint(nT) != __float_as_uint(oT);
+					const bool ch = lane < TW && __float_as_uint(nT) != __float_as_uint(oT);
 					const float p = fminf(nT, oT);
-					const uint32_t o0 = lane == 0 ? tHL : (uint32_t)(tH >> (lane - 1)) & 1u, o1 = (uint32_t)(tH >> lane) & 1u, o2 = lane == 63 ? tHR : (uint32_t)(tH >> (lane + 1)) & 1u;
-					const bool c0_ = ch && sees(p, L[lane], o0), c1_ = ch && sees(p, L[lane + 1], o1), c2_ = ch && sees(p, L[lane + 2], o2);
-					if (c1_ || (lane > 0 && c0_) || (lane < 63 && c2_))
+					const uint32_t o0 = lc == 0 ? tHL : (uint32_t)(tH >> (lc - 1)) & 1u, o1 = (uint32_t)(tH >> lc) & 1u, o2 = lc == TW - 1 ? tHR : (uint32_t)(tH >> (lc + 1)) & 1u;
+					const bool c0_ = ch && sees(p, L[lc], o0), c1_ = ch && sees(p, L[lc + 1], o1), c2_ = ch && sees(p, L[lc + 2], o2);
+					if (c1_ || (lc > 0 && c0_) || (lc < TW - 1 && c2_))
 						pN = p;
-					if (lane == 0 && c0_)
+					if (lc == 0 && c0_)
 						pNW = p;
-					if (lane == 63 && c2_)
+					if (lc == TW - 1 && c2_)
 						pNE = p;
 				}
 				{ // bottom row
-					const bool ch = __float_as_uint(nB) != __float_as_uint(oB);
+					const bool ch = lane < TW && __float_as_uint(nB) != __float_as_uint(oB);
 					const float p = fminf(nB, oB);
 					const float* const Lb = L + (TT + 1) * LS;
-					const uint32_t o0 = lane == 0 ? bHL : (uint32_t)(bH >> (lane - 1)) & 1u, o1 = (uint32_t)(bH >> lane) & 1u, o2 = lane == 63 ? bHR : (uint32_t)(bH >> (lane + 1)) & 1u;
-					const bool c0_ = ch && sees(p, Lb[lane], o0), c1_ = ch && sees(p, Lb[lane + 1], o1), c2_ = ch && sees(p, Lb[lane + 2], o2);
-					if (c1_ || (lane > 0 && c0_) || (lane < 63 && c2_))
+					const uint32_t o0 = lc == 0 ? bHL : (uint32_t)(bH >> (lc - 1)) & 1u, o1 = (uint32_t)(bH >> lc) & 1u, o2 = lc == TW - 1 ? bHR : (uint32_t)(bH >> (lc + 1)) & 1u;
+					const bool c0_ = ch && sees(p, Lb[lc], o0), c1_ = ch && sees(p, Lb[lc + 1], o1), c2_ = ch && sees(p, Lb[lc + 2], o2);
+					if (c1_ || (lc > 0 && c0_) || (lc < TW - 1 && c2_))
 						pS = p;
-					if (lane == 0 && c0_)
+					if (lc == 0 && c0_)
 						pSW = p;
-					if (lane == 63 && c2_)
+					if (lc == TW - 1 && c2_)
 						pSE = p;
 				}
 				{ // left column, lane = row
@@ -452,7 +513,7 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 				{ // right column
 					const bool ch = __float_as_uint(nR) != __float_as_uint(oR);
 					const float p = fminf(nR, oR);
-					const bool c0_ = ch && sees(p, L[lane * LS + TT + 1], occRU), c1_ = ch && sees(p, L[(lane + 1) * LS + TT + 1], occR), c2_ = ch && sees(p, L[(lane + 2) * LS + TT + 1], occRD);
+					const bool c0_ = ch && sees(p, L[lane * LS + TW + 1], occRU), c1_ = ch && sees(p, L[(lane + 1) * LS + TW + 1], occR), c2_ = ch && sees(p, L[(lane + 2) * LS + TW + 1], occRD);
 					if (c1_ || (lane > 0 && c0_) || (lane < 63 && c2_))
 						pE = p;
 					if (lane == 0 && c0_)
@@ -480,15 +541,17 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 					queue(1, 1, qSE);
 				}
 			}
+			TILE_STAMP(3) // neighbours re-queued
 			// ---- the tile's costs to the output field: whole 256-byte lines (8 x 8-tiled field: one field tile per step; row-major: one row)
-			for (int u = 0; u < TT; u++) {
+			for (int u = 0; u < TW; u++) {
 				int i, j;
-				tile_cell(A.tiledOut, u * TT + lane, i, j);
+				tile_cell<TW>(A.tiledOut, u * TT + lane, i, j);
 				const int r = r0 + i, c = c0 + j;
 				if (r < rows && c < cols)
 					cost[out_index(r, c)] = L[(i + 1) * LS + j + 1];
 			}
 			wave_sync();
+			TILE_STAMP(4) // stores issued
 		}
 		flagged = __ballot(flagged) != 0ull;
 		// ---- +inf for the tiles the wavefront never reached (heuristics.cpp:108-113)
@@ -497,10 +560,10 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 				if (tstate[t] & 1)
 					continue;
 				const int tr = t / TC, tc = t - tr * TC;
-				for (int u = 0; u < TT; u++) {
+				for (int u = 0; u < TW; u++) {
 					int i, j;
-					tile_cell(A.tiledOut, u * TT + lane, i, j);
-					const int r = tr * TT + i, c = tc * TT + j;
+					tile_cell<TW>(A.tiledOut, u * TT + lane, i, j);
+					const int r = tr * TT + i, c = tc * TW + j;
 					if (r < rows && c < cols)
 						cost[out_index(r, c)] = kInf;
 				}
@@ -535,15 +598,19 @@ __global__ void __launch_bounds__(64) k_wavefront_tiles(TilesArgs A)
 		atomicAdd(A.stats + 2, stRounds);
 		atomicAdd(A.stats + 3, stPasses);
 		atomicAdd(A.stats + 5, stFb);
-		atomicAdd(A.stats + 6, (unsigned long long)(clock64() - t0));
+		atomicAdd(A.stats + 6, (unsigned long long)(__builtin_readcyclecounter() - t0));
+		if (kProf)
+			for (int i = 0; i < 5; i++)
+				atomicAdd(A.stats + 8 + i, ph[i]);
 	}
+#undef TILE_STAMP
 	if (A.stats)
 		atomicAdd(A.stats + 4, stCells); // (counted per lane)
 	// the last wave to leave sets the goal counter back for the stream's next launch (the number of handed-over goals stays: the
 	// ordered kernel's launch behind this one reads it and sets it back in turn)
 	if (lane == 0) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-		if (__hip_atomic_fetch_add(A.ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+		if (__hip_atomic_fetch_add(A.ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)(gridDim.x * (blockDim.x >> 6)) - 1) {
 			__hip_atomic_store(A.ctl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			__hip_atomic_store(A.ctl + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
@@ -583,10 +650,68 @@ __global__ void __launch_bounds__(512) k_order_by_key(int n, const float* __rest
 		orderOut[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)skey[i]);
 }
 
+int tile_width()
+{
+	static const int w = [] {
+		const char* e = getenv("PP_WF_TILE_WIDTH"); // 64 or 32 columns per tile
+		return e && atoi(e) == 64 ? 64 : (e && atoi(e) == 32 ? 32 : PP_WF_TILE_WIDTH_DEFAULT);
+	}();
+	return w;
+}
+
 size_t tiles_lds_bytes(int rows, int cols)
 {
-	const size_t nTiles = (size_t)((rows + TT - 1) / TT) * (size_t)((cols + TT - 1) / TT);
-	return ((size_t)LNP * 4 + nTiles * 4 + nTiles + 15) & ~(size_t)15;
+	const int tw = tile_width();
+	const size_t nTiles = (size_t)((rows + TT - 1) / TT) * (size_t)((cols + tw - 1) / tw);
+	return ((size_t)(tw == 64 ? TileShape<64>::LNP : TileShape<32>::LNP) * 4 + nTiles * 4 + nTiles + 15) & ~(size_t)15;
+}
+
+/// waves per workgroup: as many as make the workgroup's LDS exceed half of a CU's 160 KB (see k_wavefront_tiles), at most 8
+int waves_per_pack(size_t ldsPerWave)
+{
+	static const int forced = [] {
+		const char* e = getenv("PP_WF_TILES_PACK"); // tuning: waves per workgroup (1..8)
+		return e ? atoi(e) : 0;
+	}();
+	if (forced >= 1 && forced <= 8)
+		return forced;
+	int n = (int)((80 * 1024) / ldsPerWave) + 1;
+	while (n > 1 && (size_t)n * ldsPerWave > 160 * 1024)
+		n--;
+	return n > 8 ? 8 : n;
+}
+
+void launch_tiles_kernel(hipStream_t s, int waves, TilesArgs A)
+{
+	const size_t lds = tiles_lds_bytes(A.m.rows, A.m.cols);
+	const int pack = waves_per_pack(lds);
+	A.ldsPerWave = (int)lds;
+	static const int prio = [] {
+		const char* e = getenv("PP_WF_TILES_PRIO");
+		const int v = e ? atoi(e) : PP_WF_TILES_PRIO_DEFAULT;
+		return v < 0 ? 0 : (v > 3 ? 3 : v);
+	}();
+	A.prio = prio;
+	const int grid = (waves + pack - 1) / pack;
+	static const bool attr = [] { // a pack's dynamic LDS goes beyond the 64 KB a launch gets without asking
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		return true;
+	}();
+	(void)attr;
+	if (tile_width() == 64) {
+		if (A.stats)
+			hipLaunchKernelGGL((k_wavefront_tiles<64, true>), dim3(grid), dim3(64 * pack), lds * pack, s, A);
+		else
+			hipLaunchKernelGGL((k_wavefront_tiles<64, false>), dim3(grid), dim3(64 * pack), lds * pack, s, A);
+	} else {
+		if (A.stats)
+			hipLaunchKernelGGL((k_wavefront_tiles<32, true>), dim3(grid), dim3(64 * pack), lds * pack, s, A);
+		else
+			hipLaunchKernelGGL((k_wavefront_tiles<32, false>), dim3(grid), dim3(64 * pack), lds * pack, s, A);
+	}
 }
 
 } // namespace
@@ -608,17 +733,22 @@ hipError_t launch_occ_bits(hipStream_t s, const uint8_t* occ8, int rows, int col
 	return hipGetLastError();
 }
 
-bool wavefront_tiles_supported(int rows, int cols) { return tiles_lds_bytes(rows, cols) <= 64 * 1024; }
+bool wavefront_tiles_supported(int rows, int cols) { return tiles_lds_bytes(rows, cols) <= 64 * 1024; } // (dynamic LDS of a launch: packs of waves, <= 160 KB)
 
 int wavefront_tiles_resident_blocks(int rows, int cols)
 {
+	// waves of the tile form that can be resident at once: packs per CU (occupancy API) x waves per pack x CUs
 	int perCu = 0, dev = 0;
 	hipDeviceProp_t prop;
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-		return 2048;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles, 64, tiles_lds_bytes(rows, cols)) != hipSuccess || perCu < 1)
+		return 1024;
+	const size_t lds = tiles_lds_bytes(rows, cols);
+	const int pack = waves_per_pack(lds);
+	const hipError_t e = tile_width() == 64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles<64, false>, 64 * pack, lds * pack)
+	                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles<32, false>, 64 * pack, lds * pack);
+	if (e != hipSuccess || perCu < 1)
 		perCu = 1;
-	return perCu * prop.multiProcessorCount;
+	return perCu * pack * prop.multiProcessorCount;
 }
 
 hipError_t warm_up_wavefront_tiles(hipStream_t s, const MapView& m, int* ctlDev)
@@ -626,7 +756,7 @@ hipError_t warm_up_wavefront_tiles(hipStream_t s, const MapView& m, int* ctlDev)
 	TilesArgs A {};
 	A.m = m;
 	A.ctl = ctlDev; // nGoals = 0: the wave reads the goal counter, finds nothing and leaves
-	hipLaunchKernelGGL(k_wavefront_tiles, dim3(1), dim3(64), tiles_lds_bytes(m.rows, m.cols), s, A);
+	launch_tiles_kernel(s, 1, A);
 	return hipGetLastError();
 }
 
@@ -664,7 +794,7 @@ hipError_t launch_wavefront_tiles(hipStream_t s, const MapView& m, int nGoals, c
 		if (g > 0 && g < grid)
 			grid = g;
 	}
-	hipLaunchKernelGGL(k_wavefront_tiles, dim3(grid), dim3(64), tiles_lds_bytes(m.rows, m.cols), s, A);
+	launch_tiles_kernel(s, grid, A);
 	return hipGetLastError();
 }
 

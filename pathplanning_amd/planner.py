@@ -422,16 +422,20 @@ class ObstaclesHeuristic:
         g = _f64(goals_xy, 2)
         check(self.lib.pp_obstacle_heuristic_dev(self.map.h, len(g), ptr(g), _dev_ptr(cost_tensor)))
 
-    TILE_STATS = ("goals", "tile_visits", "rounds", "candidate_passes", "cells", "handed_over", "wave_cycles", "tiles_per_goal")
+    TILE_STATS = ("goals", "tile_visits", "rounds", "candidate_passes", "cells", "handed_over", "wave_cycles", "tiles_per_goal",
+                  "cycles_load", "cycles_masks", "cycles_passes", "cycles_requeue", "cycles_store")
 
     def update_dev_tile_stats(self, goals_xy, cost_tensor):
         """The fields into cost_tensor like update_dev, through the tile form of the wavefront with its work counters:
         returns (dict of TILE_STATS, launch milliseconds)."""
         g = _f64(goals_xy, 2)
-        st = np.zeros(8, dtype=np.uint64)
+        st = np.zeros(16, dtype=np.uint64)
         ms = C.c_float(0.0)
-        check(self.lib.pp_obstacle_heuristic_tiles_stats(self.map.h, len(g), ptr(g), _dev_ptr(cost_tensor), ptr(st), C.byref(ms)))
-        return dict(zip(self.TILE_STATS, (int(x) for x in st))), float(ms.value)
+        handed = np.full(len(g), -1, dtype=np.int32)
+        check(self.lib.pp_obstacle_heuristic_tiles_stats(self.map.h, len(g), ptr(g), _dev_ptr(cost_tensor), ptr(st), C.byref(ms), ptr(handed)))
+        d = dict(zip(self.TILE_STATS, (int(x) for x in st)))
+        d["handed_over_goals"] = sorted(int(x) for x in handed[:d["handed_over"]])
+        return d, float(ms.value)
 
 
 class Tree:

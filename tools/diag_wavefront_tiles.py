@@ -53,7 +53,9 @@ def main():
     rec = dict(n_goals=n_goals, cells=cells, obstacles=obstacles, ms_per_launch=msl, all_runs_ms=[r[1] for r in runs], algorithmic_GBps=gbs, frac_of_8TBps=gbs / 8000.0,
                visits_per_tile=st["tile_visits"] / max(1, tiles), rounds_per_visit=st["rounds"] / max(1, st["tile_visits"]),
                passes_per_round=st["candidate_passes"] / max(1, st["rounds"]), cells_per_pass=st["cells"] / max(1, st["candidate_passes"]),
-               handed_over=st["handed_over"], wave_ms_per_goal=st["wave_cycles"] / max(1, st["goals"]) / 100e3, counters=st)
+               handed_over=st["handed_over"], handed_over_goals=[(i, [float(x) for x in goals[i]]) for i in st["handed_over_goals"]],
+               wave_cycles_per_goal=st["wave_cycles"] / max(1, st["goals"]),
+               phase_share={k[7:]: st[k] / max(1, st["wave_cycles"]) for k in st if k.startswith("cycles_")}, counters=st)
     print(json.dumps(rec))
 
 
