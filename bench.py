@@ -214,6 +214,12 @@ def main():
 
     backlog = []  # (ready, searching) samples of the last run_steps_pipeline
     tail_marks, tail_info = [], {}
+    PATH_POSES = 256  # poses fetched per plan (the longest path of the benchmark's queries has ~150 nodes)
+    path_buf = np.empty((8192, PATH_POSES, 3))
+    path_n = np.zeros(8192, dtype=np.int32)
+    last_paths = np.zeros((B, PATH_POSES, 3))  # the last step's plans, by query index
+    last_path_n = np.zeros(B, dtype=np.int32)
+    path_stats = {}
 
     def run_steps_pipeline(k):
         """k steps = k x B queries through the library's pipeline: submitted as slots are free, polled in completion order.  Returns the
@@ -226,6 +232,7 @@ def main():
         backlog.clear()
         tail_marks.clear()
         late = []
+        path_stats.update(paths=0, poses=0, longest=0, truncated=0, with_solution=0)
         t_run0 = time.perf_counter()
         last_submit = [0.0]
         while done < total:
@@ -239,12 +246,22 @@ def main():
                         base = first
                     submitted += kk
                     last_submit[0] = time.perf_counter() - t_run0
-            tickets, res = pipe.poll_array(8192)
+            # every plan leaves the GPU inside the measured region: the slots are held until their paths (GetGraphSearchPath: the poses of the
+            # solution's nodes, start first) have been copied out of the pipeline's ring in pinned host memory, then released
+            tickets, res = pipe.poll_array_held(8192)
             backlog.append(pipe.backlog())
             if len(tickets):
+                poses, n_poses = pipe.get_paths(tickets, max_poses=PATH_POSES, release=True, out=path_buf, n_out=path_n)
+                path_stats["paths"] += len(tickets)
+                path_stats["with_solution"] = path_stats.get("with_solution", 0) + int((n_poses > 0).sum())
+                path_stats["poses"] += int(np.minimum(n_poses, PATH_POSES).sum())
+                path_stats["longest"] = max(path_stats["longest"], int(n_poses.max()))
+                path_stats["truncated"] += int((n_poses > PATH_POSES).sum())
                 idx = (tickets - np.uint64(base)).astype(np.int64)
                 in_last = idx >= (k - 1) * B
                 last[idx[in_last] - (k - 1) * B] = res[in_last]
+                last_paths[idx[in_last] - (k - 1) * B] = poses[in_last]
+                last_path_n[idx[in_last] - (k - 1) * B] = n_poses[in_last]
                 sums["success"] += int((res["status"] == 0).sum())
                 sums["expansions"] += int(res["n_expanded"].sum())
                 sums["rs_attempts"] += int(res["n_rs_attempts"].sum())
@@ -428,6 +445,12 @@ def main():
             alone_gbs = B * cells * WAVEFRONT_BYTES_PER_CELL / (wf_alone_ms * 1e-3) / 1e9
             roofs["k_wavefront"]["alone"] = dict(ms_per_launch=wf_alone_ms, goals=B, achieved=alone_gbs, frac=alone_gbs / HBM_PEAK_GBS)
         roofs["search"]["busy_ms_per_step"] = elapsed * 1e3 / args.steps
+        # per step: the bytes of everything the kernel did in the run / the timed region (whatever its launches' overlap)
+        for key, nbytes in (("k_wavefront", pipe_kernel["wavefront_goals"] * cells * WAVEFRONT_BYTES_PER_CELL), ("search", se_bytes)):
+            gbs = nbytes / elapsed / 1e9
+            roofs[key]["per_step"] = dict(algorithmic_bytes_per_step=nbytes / args.steps, ms_per_step=elapsed * 1e3 / args.steps, achieved=gbs, frac=gbs / HBM_PEAK_GBS)
+        roofs["both_kernels_per_step"] = dict(achieved=sum(roofs[k]["per_step"]["achieved"] for k in ("k_wavefront", "search")),
+                                              frac=sum(roofs[k]["per_step"]["frac"] for k in ("k_wavefront", "search")))
         roof = roofs["k_wavefront"] if wf_busy_per_step >= elapsed * 1e3 / args.steps else roofs["search"]
     else:
         roof = roofs["k_wavefront"] if wf >= se else roofs["search"]
@@ -437,7 +460,9 @@ def main():
         try:
             tr = json.load(open(tj))
             for r_ in roofs.values():
-                r_["traffic"] = tr.get(r_["kernel"].split("<")[0].split(" ")[0])
+                if "kernel" in r_:
+                    r_["traffic"] = tr.get(r_["kernel"].split("<")[0].split(" ")[0])
+                    r_["l2_hit"] = tr.get("l2_hit", {}).get(r_["kernel"].split("<")[0].split(" ")[0])
         except Exception:
             pass
 
@@ -452,12 +477,26 @@ def main():
             ow.set_d2(m["d2"])
             ow.set_pathcost(m["path_cost"])
             # the oracle plans with ITS OWN non-holonomic table (glibc), as the reference would -- not with the device-built one
-            table, _ = O.nonholo_build(ow.lb, ow.ub, O.params_array(), threads=min(os.cpu_count() or 1, 16))
+            host_cpus = os.cpu_count() or 1
+            usable = host_cpus  # the hardware threads this job may actually use: affinity mask and cgroup CPU quota (a GPU box grants a share of its host)
+            try:
+                usable = min(usable, len(os.sched_getaffinity(0)))
+            except (AttributeError, OSError):
+                pass
+            for cg in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+                try:
+                    txt = open(cg).read().split()
+                    if cg.endswith("cpu.max"):
+                        quota, period = txt[0], float(txt[1])
+                    else:
+                        quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    if quota not in ("max", "-1") and float(quota) > 0:
+                        usable = max(1, min(usable, int(float(quota) / period + 0.5)))
+                    break
+                except (OSError, ValueError, IndexError):
+                    continue
+            table, _ = O.nonholo_build(ow.lb, ow.ub, O.params_array(), threads=min(usable, 64))
             table_equal = bool(np.array_equal(table, planner.nonholo_table()))
-            ns = min(args.cpu_sample, B)
-            cores = min(os.cpu_count() or 1, 16)
-            secs, st, cost, nexp = O.hybrid_batch(ow, table, starts[:ns], goals[:ns], seeds[:ns], threads=cores)
-            agree = sum(1 for i in range(ns) if st[i] == res[i].status and (st[i] != 0 or abs(cost[i] - res[i].cost) < 1e-5) and nexp[i] == res[i].n_expanded)
             model = ""
             try:
                 for ln in open("/proc/cpuinfo"):
@@ -466,9 +505,27 @@ def main():
                         break
             except OSError:
                 pass
-            cpu = dict(value=ns / secs, unit="plans/s", cores=cores, cpu_model=model, host_cpus=os.cpu_count(), kind="port",
-                       sample="first %d of the %d benchmark queries, oracle HybridAStar::Search (heap wavefront + graph search), %d threads" % (ns, B, cores),
-                       agree_with_gpu="%d/%d" % (agree, ns), oracle_table="own (glibc)", device_table_identical_to_oracle_table=table_equal)
+            # (i) one thread, (ii) all host cores (one planner instance per thread, queries sharded).  Bounded samples: the first
+            # --cpu-sample queries on one thread (~2 plans/s), the first 1024 on every hardware thread.
+            n1 = min(args.cpu_sample // 4 if args.cpu_sample >= 8 else args.cpu_sample, B)
+            secs1, st1, cost1, nexp1 = O.hybrid_batch(ow, table, starts[:n1], goals[:n1], seeds[:n1], threads=1)
+            ns = min(max(args.cpu_sample, 1024) if args.cpu_sample >= 192 else args.cpu_sample, B)
+            secs, st, cost, nexp, oposes, on = O.hybrid_batch_paths(ow, table, starts[:ns], goals[:ns], seeds[:ns], threads=usable, max_poses=PATH_POSES if pipeline_mode else 256)
+            agree = sum(1 for i in range(ns) if st[i] == res[i].status and (st[i] != 0 or abs(cost[i] - res[i].cost) < 1e-5) and nexp[i] == res[i].n_expanded)
+            agree1 = sum(1 for i in range(n1) if st1[i] == st[i] and nexp1[i] == nexp[i])
+            paths_agree = None
+            if pipeline_mode:  # the plans the GPU delivered in the last step against the oracle's: node counts equal, poses within 1e-5
+                paths_agree = 0
+                for i in range(ns):
+                    k_ = min(int(on[i]), PATH_POSES)
+                    if int(on[i]) == int(last_path_n[i]) and (k_ == 0 or float(np.abs(oposes[i, :k_] - last_paths[i, :k_]).max()) < 1e-5):
+                        paths_agree += 1
+            cpu = dict(value=ns / secs, unit="plans/s", cores=usable, cpu_model=model, host_cpus=host_cpus, usable_cpus=usable, kind="port",
+                       sample="first %d of the %d benchmark queries on %d threads = every hardware thread this job may use (affinity mask and cgroup CPU quota; the host has %d), oracle HybridAStar::Search (heap wavefront + graph search), one planner per thread" % (ns, B, usable, host_cpus),
+                       all_cores=dict(value=ns / secs, threads=usable, queries=ns, seconds=secs),
+                       one_thread=dict(value=n1 / secs1, threads=1, queries=n1, seconds=secs1, same_outcome_as_all_cores_run="%d/%d" % (agree1, n1)),
+                       agree_with_gpu="%d/%d" % (agree, ns), paths_agree_with_gpu=None if paths_agree is None else "%d/%d" % (paths_agree, ns),
+                       oracle_table="own (glibc)", device_table_identical_to_oracle_table=table_equal)
         except Exception as e:  # the bench line must still be printed
             cpu = dict(value=None, unit="plans/s", cores=0, kind="port", sample="failed: %r" % (e,))
 
@@ -488,7 +545,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "Hybrid A* batch of %d start/goal pairs per GPU per step on one %dx%d map (res 0.1 m, %d rectangle outlines), P=%d constant-steer primitives + RS analytic expansion, exact-order obstacle heuristic per query" % (B, args.cells, args.cells, args.obstacles, planner.num_primitives),
+            "config": {"workload": "Hybrid A* batch of %d start/goal pairs per GPU per step on one %dx%d map (res 0.1 m, %d rectangle outlines), P=%d constant-steer primitives + RS analytic expansion, exact-order obstacle heuristic per query; every step replays one fixed set of %d queries (seeds 0..%d) and every plan's path is copied to the host inside the timed region" % (B, args.cells, args.cells, args.obstacles, planner.num_primitives, B, B - 1),
                        "queries_per_gpu": B, "grid": [ms.rows, ms.cols], "parallelism": "query-sharded x%d" % n_gpus,
                        **({"scheduler": "library pipeline (pp_pipeline_*)", "queries_in_flight": pipe.capacity, "search_rows": pipe.search_rows} if pipeline_mode
                           else {"scheduler": "bench.py lanes", "batches_in_flight": n_streams, "lane_stagger_ms": round(stagger_ms[0], 1)})},
@@ -510,6 +567,8 @@ def main():
             **({"pipeline_kernel_timings": pipe_kernel, "run_totals": run_sums,
                 "replay_consistent": bool(run_sums["expansions"] == args.steps * n_expanded and run_sums["success"] == args.steps * n_success and
                                           run_sums["rng_draws"] == args.steps * sum(r.n_rng_draws for r in res) and run_sums["state_checks"] == args.steps * state_checks),
+                "paths_fetched": path_stats.get("paths"), "paths_with_solution": path_stats.get("with_solution"), "path_poses_fetched": path_stats.get("poses"), "longest_path_nodes": path_stats.get("longest"),
+                "paths_longer_than_fetched": path_stats.get("truncated"),
                 "run_profile": dict(tail_info), "pipeline_backlog": dict(samples=len(backlog), ready_mean=float(np.mean([b[0] for b in backlog])), ready_p10=float(np.percentile([b[0] for b in backlog], 10)),
                                          ready_max=int(max(b[0] for b in backlog)), searching_mean=float(np.mean([b[1] for b in backlog])), rows=pipe.search_rows)} if pipeline_mode else {}),
             "cpu_baseline": cpu,

@@ -372,6 +372,12 @@ int pp_pipeline_submit(pp_pipeline* pipeline, int32_t n_queries, const double* s
  * read its path) until pp_pipeline_release. */
 int pp_pipeline_poll(pp_pipeline* pipeline, int32_t max_results, uint64_t* tickets_out, pp_query_result* results_out, int32_t release, int32_t* n_out);
 int pp_pipeline_release(pp_pipeline* pipeline, int32_t n, const uint64_t* tickets);
+/* The plans themselves: GetGraphSearchPath (hybrid_a_star.h:223, a_star.h:254-288) of n completed, held queries (polled with release == 0), start
+ * pose first.  poses_host: [n][max_poses][3] doubles (x, y, theta), n_poses_host[i] = nodes on path i (0: no solution; it may exceed max_poses,
+ * then only the first max_poses are written).  The row that finishes a query writes its path's poses (up to PP_PIPE_PATH_POSES = 192 per query)
+ * into a ring in pinned host memory together with the completion record, so this call copies host memory: no kernel, no device copy (a longer
+ * path's remaining records are fetched from the device).  release != 0: the slots are returned like pp_pipeline_release. */
+int pp_pipeline_get_paths(pp_pipeline* pipeline, int32_t n, const uint64_t* tickets, int32_t max_poses, double* poses_host, int32_t* n_poses_host, int32_t release);
 int pp_pipeline_slot_of(pp_pipeline* pipeline, uint64_t ticket); /* -1 unless completed and held */
 pp_planner* pp_pipeline_planner(pp_pipeline* pipeline);           /* the buffer set: set_nonholo_table, set_primitives, get_path(slot), ... */
 int pp_pipeline_capacity(pp_pipeline* pipeline);

@@ -803,6 +803,46 @@ double ppo_hybrid_batch(void* wv, const double* params, int headingAlias, int ne
 	return std::chrono::duration<double>(t1 - t0).count();
 }
 
+/// ppo_hybrid_batch that also returns every solution path (GetGraphSearchPath, hybrid_a_star.h:223: the poses of the nodes root..solution):
+/// poses [n][maxPoses][3], nPoses [n] (0: no solution; a longer path is cut at maxPoses).  bench.py's cpu_baseline leg checks the paths the
+/// GPU pipeline delivered against these.
+double ppo_hybrid_batch_paths(void* wv, const double* params, int headingAlias, int negativeKRead, const double* table, int64_t n, const double* starts,
+	const double* goals, const uint64_t* seeds, int threads, int* status, double* cost, int64_t* nExpanded, int maxPoses, double* poses, int* nPoses)
+{
+	World* w = (World*)wv;
+	if (threads < 1)
+		threads = 1;
+	std::vector<std::unique_ptr<HybridHandle>> hs;
+	for (int t = 0; t < threads; t++) {
+		hs.emplace_back((HybridHandle*)ppo_hybrid_create(w, params, headingAlias, negativeKRead));
+		ppo_hybrid_initialize(hs.back().get(), table);
+	}
+	auto t0 = std::chrono::steady_clock::now();
+	auto work = [&](int t) {
+		for (int64_t i = t; i < n; i += threads) {
+			HybridResult r = hs[t]->algo->Search(P3(starts + 3 * i), P3(goals + 3 * i), seeds[i]);
+			status[i] = r.status;
+			cost[i] = r.cost;
+			nExpanded[i] = (int64_t)r.expanded.size();
+			nPoses[i] = r.status == 0 ? (int)r.pathNodes.size() : 0;
+			for (int k = 0; k < nPoses[i] && k < maxPoses; k++) {
+				const HybridNode& nd = hs[t]->algo->nodes[r.pathNodes[(size_t)k]];
+				double* o = poses + ((size_t)i * (size_t)maxPoses + (size_t)k) * 3;
+				o[0] = nd.pose.x;
+				o[1] = nd.pose.y;
+				o[2] = nd.pose.theta;
+			}
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int t = 0; t < threads; t++)
+		pool.emplace_back(work, t);
+	for (auto& th : pool)
+		th.join();
+	auto t1 = std::chrono::steady_clock::now();
+	return std::chrono::duration<double>(t1 - t0).count();
+}
+
 // -------------------------------------------------------------- grid A* ----
 typedef double (*ppo_cell_fn)(int, int, int, int);
 static double EuclidCells(const Cell& a, const Cell& b)

@@ -172,6 +172,7 @@ def load():
     L.pp_pipeline_submit.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
     L.pp_pipeline_poll.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, vp]
     L.pp_pipeline_release.argtypes = [vp, C.c_int32, vp]
+    L.pp_pipeline_get_paths.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, vp, C.c_int32]
     L.pp_pipeline_slot_of.argtypes = [vp, C.c_uint64]
     L.pp_pipeline_timings.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.pp_pipeline_backlog.argtypes = [vp, vp, vp]

@@ -23,6 +23,7 @@
 #pragma once
 
 #include <chrono>
+#include <deque>
 #include <unordered_map>
 
 namespace {
@@ -101,6 +102,16 @@ struct pp_pipeline {
 	                                      // ring; 0 = none; < 0 = twice the validator's minimum safe radius (2 m with the reference's default)
 	int32_t* slotLists = nullptr; // ring of slot lists, one segment per wavefront launch in flight
 	size_t slotListCap = 0, slotListPos = 0;
+	// the segments of the launches that may not have finished, oldest first, each with an event recorded behind its launch: a segment is
+	// not written again before its launch is done (a launch queued behind long ones reads its list late, and with the urgent ring a slot
+	// can be built, searched, polled and refilled many times meanwhile -- capacity alone does not bound the entries submitted since)
+	struct Segment {
+		size_t begin = 0, end = 0;
+		hipEvent_t done = nullptr;
+	};
+	std::deque<Segment> segments;
+	std::vector<hipEvent_t> segmentEvents; // spare events
+	long long segmentWaits = 0;            // times a submission had to wait for a launch before reusing its segment (diagnostic)
 	void* wfWorkspace[kPipeWavefrontStreams] = {};
 	int32_t* wfCtl[kPipeWavefrontStreams] = {}; // per wavefront stream: {error flag, goal counter, exit counter, -, then the tile form's eight control words}
 	int32_t* wfFallback[kPipeWavefrontStreams] = {}; // per wavefront stream, [capacity]: the goals the tile form hands to the ordered kernel
@@ -111,6 +122,9 @@ struct pp_pipeline {
 	unsigned long long* submittedStage = nullptr; // ring of submission counts on their way to ctl->nSubmitted
 	int submittedStagePos = 0;
 	int32_t* errFlags = nullptr; // [streams] the wavefront kernels' error flags, in pinned host memory: written by the device, read by poll
+	double* pathHost = nullptr;  // [capacity][pathHostCap][3]: the poses of every finished query's solution path, goal first, written by the row that finished it
+	int pathHostCap = 192;       // poses per slot in that ring (longer paths: the rest is fetched from the device records); PP_PIPE_PATH_POSES
+	bool dead = false;           // a submission failed half way: the pipeline's accounting is no longer trustworthy (every later call fails)
 	unsigned long long lastTail = 0, lastHead = 0; // the ready queue's counters as the latest completion record saw them
 	// streams
 	hipStream_t wfStream[kPipeWavefrontStreams] = {}, searchStream[kPipeSearchStreams] = {}, ctlStream = nullptr;
@@ -156,6 +170,11 @@ void free_pipeline(pp_pipeline* P)
 		(void)hipEventDestroy(P->evIngest);
 	if (P->evCtl)
 		(void)hipEventDestroy(P->evCtl);
+	for (auto& sg : P->segments)
+		if (sg.done)
+			(void)hipEventDestroy(sg.done);
+	for (hipEvent_t ev : P->segmentEvents)
+		(void)hipEventDestroy(ev);
 	for (auto* v : { &P->timedFree, &P->timedBusy })
 		for (auto& t : *v) {
 			if (t.a)
@@ -167,7 +186,7 @@ void free_pipeline(pp_pipeline* P)
 	for (void* q : dev)
 		if (q)
 			(void)hipFree(q);
-	void* host[] = { P->done, P->slotStage, P->submittedStage, P->errFlags };
+	void* host[] = { P->done, P->slotStage, P->submittedStage, P->errFlags, P->pathHost };
 	for (void* q : host)
 		if (q)
 			(void)hipHostFree(q);
@@ -235,6 +254,8 @@ PipeView pipe_view(const pp_pipeline* P)
 	v.doneMask = P->doneMask;
 	v.waveAlive = P->waveAlive;
 	v.idleTicks = P->idleTicks;
+	v.pathHost = P->pathHost;
+	v.pathHostCap = P->pathHostCap;
 	return v;
 }
 
@@ -367,6 +388,15 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		e = hipHostMalloc((void**)&P->submittedStage, 64 * 8, hipHostMallocDefault);
 	if (e == hipSuccess)
 		e = hipHostMalloc((void**)&P->errFlags, 64, hipHostMallocDefault);
+	if (const char* v = getenv("PP_PIPE_PATH_POSES")) {
+		const long x = strtol(v, nullptr, 10);
+		if (x >= 0 && x <= 2048)
+			P->pathHostCap = (int)x;
+	}
+	if (P->pathHostCap > pl->maxPath)
+		P->pathHostCap = pl->maxPath;
+	if (e == hipSuccess && P->pathHostCap > 0)
+		e = hipHostMalloc((void**)&P->pathHost, (size_t)capacity * (size_t)P->pathHostCap * 24, hipHostMallocDefault);
 	if (e == hipSuccess)
 		e = hipMemset(P->ctl, 0, sizeof(PipeCtl));
 	if (e == hipSuccess)
@@ -393,6 +423,8 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	P->slotGen.assign((size_t)capacity, 0u);
 	pl->hostResults.resize((size_t)capacity);
 	pl->lastBatch = capacity;
+	pl->pipelineOwned = true;
+	pl->owner = P;
 	{
 		P->wfBlocks = pl->wfSlots;
 		if (const char* b = getenv("PP_PIPE_WF_BLOCKS")) { // tuning: fewer resident wavefront workgroups leave more of the chip to the search grid
@@ -442,6 +474,10 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 		return PP_ERR_INVALID;
 	}
 	*n_accepted = 0;
+	if (P->dead) {
+		set_error("the pipeline failed in an earlier submission and must be destroyed");
+		return PP_ERR_HIP;
+	}
 	pp_planner* pl = P->pl;
 	PP_HIP_TRY(hipSetDevice(pl->map->ctx->device));
 	if (!pl->tableReady)
@@ -454,7 +490,36 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 		return PP_OK;
 	// ---- slots and tickets
 	if (P->slotListPos + (size_t)k > P->slotListCap)
-		P->slotListPos = 0; // (a segment never wraps; segments in flight hold at most `capacity` of the 4 x capacity entries)
+		P->slotListPos = 0; // (a segment never wraps)
+	while (!P->segments.empty() && hipEventQuery(P->segments.front().done) == hipSuccess) {
+		P->segmentEvents.push_back(P->segments.front().done);
+		P->segments.pop_front();
+	}
+	for (const auto& sg : P->segments)
+		if (sg.begin < P->slotListPos + (size_t)k && P->slotListPos < sg.end) { // its launch still reads (or has yet to read) these entries
+			P->segmentWaits++;
+			PP_HIP_TRY(hipEventSynchronize(sg.done));
+		}
+	pp_pipeline::Segment seg;
+	seg.begin = P->slotListPos;
+	seg.end = P->slotListPos + (size_t)k;
+	if (!P->segmentEvents.empty()) {
+		seg.done = P->segmentEvents.back();
+		P->segmentEvents.pop_back();
+	} else {
+		PP_HIP_TRY(hipEventCreateWithFlags(&seg.done, hipEventDisableTiming));
+	}
+	// from here on a failure leaves slots taken and work half queued: the pipeline is marked dead instead of pretending to account for it
+	struct DeadGuard {
+		pp_pipeline* P;
+		bool armed = true;
+		~DeadGuard()
+		{
+			if (armed)
+				P->dead = true;
+		}
+	} guard { P };
+	P->segmentEvents.push_back(seg.done); // (owned by the pool until the launch below has been recorded)
 	int32_t* const stage = P->slotStage + P->slotListPos;
 	int32_t* const listDev = P->slotLists + P->slotListPos;
 	P->slotListPos += (size_t)k;
@@ -507,9 +572,14 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	PP_HIP_TRY(pph::launch_wavefront(w, pl->args.m, k, nullptr, pl->costFields, wws, pl->wfBytesPerSlot, P->wfBlocks, werr, nullptr, /*tiledOut=*/true, /*goalPoses=*/pl->dGoals,
 		/*countersZeroed=*/true, nullptr, nullptr, nullptr, nullptr, pub));
 	timed_done(P, w, tm);
+	PP_HIP_TRY(hipEventRecord(seg.done, w));
+	P->segmentEvents.pop_back();
+	P->segments.push_back(seg);
 	P->nSubmitted += (unsigned long long)k;
 	*n_accepted = k;
-	return pipe_launch_search(P);
+	const int rc = pipe_launch_search(P);
+	guard.armed = rc != PP_OK;
+	return rc;
 }
 
 int pp_pipeline_submit(pp_pipeline* P, int32_t n_queries, const double* starts_host, const double* goals_host, const uint64_t* seeds_host, uint64_t* tickets_out, int32_t* n_accepted)
@@ -550,6 +620,10 @@ int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out,
 		return PP_ERR_INVALID;
 	}
 	*n_out = 0;
+	if (P->dead) {
+		set_error("the pipeline failed earlier and must be destroyed");
+		return PP_ERR_HIP;
+	}
 	pp_planner* pl = P->pl;
 	int n = 0;
 	while (n < max_results) {
@@ -582,7 +656,10 @@ int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out,
 	// the wavefront kernels raise their error flags in pinned host memory: no copy, no HIP call on this path
 	if (__atomic_load_n(&P->errFlags[0], __ATOMIC_RELAXED) || __atomic_load_n(&P->errFlags[1], __ATOMIC_RELAXED) || __atomic_load_n(&P->errFlags[2], __ATOMIC_RELAXED) ||
 		__atomic_load_n(&P->errFlags[3], __ATOMIC_RELAXED)) {
-		set_error("obstacle-heuristic open list exceeded its workspace");
+		// a field could not be built (the ordered kernel's open list outgrew its workspace): that goal's query will never be announced.  The
+		// records consumed above ARE returned (*n_out), the pipeline is dead from here on.
+		P->dead = true;
+		set_error("obstacle-heuristic open list exceeded its workspace: the pipeline must be destroyed (the results returned with this call are valid)");
 		return PP_ERR_CAPACITY;
 	}
 	if (P->nSubmitted > P->doneHead) {
@@ -612,6 +689,66 @@ int pp_pipeline_release(pp_pipeline* P, int32_t n, const uint64_t* tickets)
 		P->freeSlots.push_back(it->second);
 		P->slotOfTicket.erase(it);
 	}
+	return PP_OK;
+}
+
+int pp_pipeline_get_paths(pp_pipeline* P, int32_t n, const uint64_t* tickets, int32_t max_poses, double* poses_host, int32_t* n_poses_host, int32_t release)
+{
+	if (!P || n < 0 || max_poses < 1 || (n > 0 && (!tickets || !poses_host || !n_poses_host))) {
+		set_error("invalid arguments");
+		return PP_ERR_INVALID;
+	}
+	pp_planner* pl = P->pl;
+	for (int i = 0; i < n; i++) {
+		auto it = P->slotOfTicket.find(tickets[i]);
+		if (it == P->slotOfTicket.end() || P->slotState[(size_t)it->second] != 2) {
+			set_error("ticket is not a completed, held query");
+			return PP_ERR_INVALID;
+		}
+		const int32_t slot = it->second;
+		const DevResult& r = pl->hostResults[(size_t)slot];
+		double* out = poses_host + (size_t)i * (size_t)max_poses * 3;
+		int np = r.r.status == 0 && r.solutionNode >= 0 ? r.r.n_path : 0;
+		if (np > pl->maxPath) {
+			set_error("solution path longer than the planner's path buffer");
+			return PP_ERR_CAPACITY;
+		}
+		n_poses_host[i] = np;
+		const int want = np < max_poses ? np : max_poses; // the first `want` poses of the path, start first = records np-1 .. np-want
+		const int inRing = np < P->pathHostCap ? np : P->pathHostCap; // records 0 .. inRing-1 (goal first) arrived with the completion record
+		const double* ring = P->pathHost + (size_t)slot * (size_t)P->pathHostCap * 3;
+		std::vector<PathRec> rest;
+		if (np > inRing || !P->pathHost) { // the ring holds the path's goal end; a longer path's start end comes from the device records (one copy)
+			const int first = P->pathHost ? inRing : 0;
+			rest.resize((size_t)(np - first));
+			if (np - first > 0) {
+				PP_HIP_TRY(hipSetDevice(pl->map->ctx->device));
+				PP_HIP_TRY(hipMemcpy(rest.data(), pl->paths + (size_t)slot * pl->maxPath + first, (size_t)(np - first) * sizeof(PathRec), hipMemcpyDeviceToHost));
+			}
+			for (int k = 0; k < want; k++) {
+				const int rec = np - 1 - k;
+				if (rec >= first) {
+					const PathRec& pr = rest[(size_t)(rec - first)];
+					out[3 * k] = pr.x;
+					out[3 * k + 1] = pr.y;
+					out[3 * k + 2] = pr.t;
+				} else {
+					out[3 * k] = ring[3 * rec];
+					out[3 * k + 1] = ring[3 * rec + 1];
+					out[3 * k + 2] = ring[3 * rec + 2];
+				}
+			}
+		} else {
+			for (int k = 0; k < want; k++) {
+				const int rec = np - 1 - k;
+				out[3 * k] = ring[3 * rec];
+				out[3 * k + 1] = ring[3 * rec + 1];
+				out[3 * k + 2] = ring[3 * rec + 2];
+			}
+		}
+	}
+	if (release)
+		return pp_pipeline_release(P, n, tickets);
 	return PP_OK;
 }
 

@@ -174,11 +174,18 @@ __device__ __forceinline__ void wave_vmem_sync()
 
 /// GetPath (a_star.h:254-288): walks the parent chain from the solution node; records are written goal first.
 /// Returns the number of nodes on the path (it may exceed `cap`: only the first `cap` records are stored).
-__device__ inline int write_path(const Node* nodes, int solutionNode, PathRec* out, int cap)
+/// hostPoses (pipeline: pp_pipeline_get_paths): the first hostCap poses also go, as (x, y, theta) triples in the same order, to the query's
+/// slot of a ring in pinned host memory -- the plan leaves the GPU with its completion record, no copy and no kernel at fetch time.
+__device__ inline int write_path(const Node* nodes, int solutionNode, PathRec* out, int cap, double* hostPoses = nullptr, int hostCap = 0)
 {
 	int depth = 0;
 	for (int k = solutionNode; k >= 0;) {
 		const Node nd = nodes[k];
+		if (depth < hostCap) {
+			hostPoses[3 * depth] = nd.x;
+			hostPoses[3 * depth + 1] = nd.y;
+			hostPoses[3 * depth + 2] = nd.t;
+		}
 		if (depth < cap) {
 			PathRec pr;
 			pr.x = nd.x;
@@ -1159,6 +1166,8 @@ struct PipeView {
 	PipeDone* done = nullptr;
 	unsigned long long doneMask = 0;
 	int* waveAlive = nullptr;         // [waves] 1 while a wave of some launch owns that wave index (and with it the rows' buffers)
+	double* pathHost = nullptr;       // pinned host memory, [capacity][pathHostCap][3]: the solution path's poses, goal first (write_path)
+	int pathHostCap = 0;
 	unsigned long long idleTicks = 0; // loop passes (~4 us each: a sleep and three polls) a wave waits without work before it leaves on its own
 };
 
@@ -1219,6 +1228,8 @@ struct pp_planner {
 	int directCount = 0;
 	float wavefrontMs = 0, searchMs = 0;
 	int lastBatch = 0;
+	pp_pipeline* owner = nullptr; // (set with pipelineOwned)
+	bool pipelineOwned = false; // the buffer set of a pp_pipeline (pp_pipeline_planner()): its rows and field slots belong to the pipeline's kernels
 	std::vector<DevResult> hostResults;
 	// post-processing (pp_postprocess.hpp), allocated at the first pp_planner_postprocess
 	PostBuffers post {};
@@ -1632,6 +1643,12 @@ int pp_planner_set_primitives(pp_planner* planner, int32_t n_steering_angles, co
 		set_error("invalid arguments");
 		return PP_ERR_INVALID;
 	}
+	if (planner->owner && pp_pipeline_in_flight(planner->owner) > 0) {
+		// the persistent search grid received its primitive table when its waves were launched: waves of later launches would get the new
+		// one, and a query's result would depend on which wave claims it
+		set_error("the pipeline has queries in flight: poll them all before changing the primitives");
+		return PP_ERR_INVALID;
+	}
 	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
 	PP_HIP_TRY(hipStreamSynchronize(planner->map->ctx->stream)); // a batch in flight keeps the table it was launched with
 	const std::vector<double> before = planner->deltas;
@@ -1691,6 +1708,10 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 {
 	if (!planner || n_queries < 0 || n_queries > planner->maxBatch || (n_queries > 0 && (!starts_dev || !goals_dev || !seeds_dev))) {
 		set_error("invalid arguments (n_queries must be <= max_batch)");
+		return PP_ERR_INVALID;
+	}
+	if (planner->pipelineOwned) {
+		set_error("this planner is a pipeline's buffer set (pp_pipeline_planner): queries go through pp_pipeline_submit");
 		return PP_ERR_INVALID;
 	}
 	if (n_queries == 0)
@@ -1794,6 +1815,10 @@ int pp_planner_fetch_results(pp_planner* planner, int32_t n_queries, pp_query_re
 		set_error("invalid arguments");
 		return PP_ERR_INVALID;
 	}
+	if (planner->pipelineOwned) {
+		set_error("this planner is a pipeline's buffer set: its results arrive through pp_pipeline_poll");
+		return PP_ERR_INVALID;
+	}
 	PP_HIP_TRY(hipSetDevice(planner->map->ctx->device));
 	hipStream_t s = planner->map->ctx->stream;
 	planner->hostResults.resize(planner->lastBatch);
@@ -1817,6 +1842,10 @@ int pp_planner_search_batch(pp_planner* planner, int32_t n_queries, const double
 {
 	if (!planner || n_queries < 0 || n_queries > planner->maxBatch || (n_queries > 0 && (!starts_host || !goals_host || !seeds_host || !results_host))) {
 		set_error("invalid arguments (n_queries must be <= max_batch)");
+		return PP_ERR_INVALID;
+	}
+	if (planner->pipelineOwned) {
+		set_error("this planner is a pipeline's buffer set (pp_pipeline_planner): queries go through pp_pipeline_submit");
 		return PP_ERR_INVALID;
 	}
 	if (n_queries == 0)
@@ -2188,6 +2217,10 @@ int pp_planner_get_expanded(pp_planner* planner, int32_t q, int32_t* cells_host)
 {
 	if (!planner || q < 0 || q >= planner->lastBatch || (int)planner->hostResults.size() <= q || !cells_host) {
 		set_error("no fetched result for this query (call pp_planner_fetch_results first)");
+		return PP_ERR_INVALID;
+	}
+	if (!planner->expanded) {
+		set_error("this planner keeps no expansion log (a pipeline created with log_expansions = 0)");
 		return PP_ERR_INVALID;
 	}
 	const DevResult& r = planner->hostResults[q];

@@ -330,7 +330,8 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			r.r.n_nodes = nNodes;
 			r.r.n_path = 0;
 			if (status == 0)
-				r.r.n_path = write_path(nodes, solutionNode, pathBase + (size_t)q * A.maxPath, A.maxPath);
+				r.r.n_path = write_path(nodes, solutionNode, pathBase + (size_t)q * A.maxPath, A.maxPath, piped ? pipe.pathHost + (size_t)q * (size_t)(3 * pipe.pathHostCap) : nullptr,
+					piped ? pipe.pathHostCap : 0);
 			r.r.cost = solutionCost;
 			r.r.n_rng_draws = nRngDraws;
 			r.r.n_rs_attempts = nRsAttempts;
@@ -338,8 +339,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			r.r.n_path_checks = pathChecks;
 			r.solutionNode = solutionNode;
 			r.nRsLog = nRsLog < kRsLogCap ? nRsLog : kRsLogCap;
-			if (!piped)
-				results[q] = r;
+			results[q] = r; // (pipeline: the slot's record for pp_planner_postprocess and the other accessors of pp_pipeline_planner() on a held slot)
 			if (piped) {
 				// path records, logs and the record above reach memory (the host may fetch them once it has seen the announcement), then the
 				// completion record goes to the ring in host memory, its stamp last

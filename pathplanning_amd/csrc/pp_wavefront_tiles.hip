@@ -684,7 +684,8 @@ int waves_per_pack(size_t ldsPerWave)
 void launch_tiles_kernel(hipStream_t s, int waves, TilesArgs A)
 {
 	const size_t lds = tiles_lds_bytes(A.m.rows, A.m.cols);
-	const int pack = waves_per_pack(lds);
+	// packs protect the pipeline's persistent search grid; a launch outside a pipeline has the chip to itself: single waves, eight per CU
+	const int pack = A.pub.ready ? waves_per_pack(lds) : 1;
 	A.ldsPerWave = (int)lds;
 	static const int prio = [] {
 		const char* e = getenv("PP_WF_TILES_PRIO");
@@ -743,7 +744,7 @@ int wavefront_tiles_resident_blocks(int rows, int cols)
 	if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
 		return 1024;
 	const size_t lds = tiles_lds_bytes(rows, cols);
-	const int pack = waves_per_pack(lds);
+	const int pack = 1; // (an upper bound: single-wave workgroups, launch_tiles_kernel; packs hold fewer)
 	const hipError_t e = tile_width() == 64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles<64, false>, 64 * pack, lds * pack)
 	                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles<32, false>, 64 * pack, lds * pack);
 	if (e != hipSuccess || perCu < 1)

@@ -712,6 +712,31 @@ class HybridAStarPipeline:
         check(self.lib.pp_pipeline_poll(self.h, int(max_results), ptr(tickets), ptr(res), 1, C.byref(k)))
         return tickets[:k.value], res[:k.value]
 
+    def poll_array_held(self, max_results=4096):
+        """poll(release=False) as numpy arrays: the slots stay held until get_paths(..., release=True) / release(); for callers that fetch
+        every plan (bench.py)"""
+        from ._lib import QUERY_RESULT_DTYPE
+        tickets = np.empty(max_results, dtype=np.uint64)
+        res = np.empty(max_results, dtype=QUERY_RESULT_DTYPE)
+        k = C.c_int32(0)
+        check(self.lib.pp_pipeline_poll(self.h, int(max_results), ptr(tickets), ptr(res), 0, C.byref(k)))
+        return tickets[:k.value], res[:k.value]
+
+    def get_paths(self, tickets, max_poses=256, release=True, out=None, n_out=None):
+        """GetGraphSearchPath of completed, held queries, start pose first (pp_pipeline_get_paths): returns (poses [k, max_poses, 3] f64,
+        n_poses [k] int32); rows beyond n_poses[i] are unspecified.  The poses arrive in pinned host memory with the completion records:
+        this is a host copy."""
+        t = np.ascontiguousarray(tickets, dtype=np.uint64)
+        k = len(t)
+        poses = out if out is not None else np.empty((max(k, 1), max_poses, 3))
+        n_poses = n_out if n_out is not None else np.zeros(max(k, 1), dtype=np.int32)
+        assert poses.flags.c_contiguous and poses.shape[0] >= k and poses.shape[1] == max_poses
+        check(self.lib.pp_pipeline_get_paths(self.h, k, ptr(t), int(max_poses), ptr(poses), ptr(n_poses), int(bool(release))))
+        if release:
+            for x in t:
+                self._held.pop(int(x), None)
+        return poses[:k], n_poses[:k]
+
     def backlog(self):
         """(ready, searching): queries whose field is built and waiting for a row / claimed by a row, as of the last poll"""
         a, b = C.c_int64(0), C.c_int64(0)
@@ -747,6 +772,35 @@ class HybridAStarPipeline:
         if n:
             check(self.lib.pp_planner_get_path(self.planner_h, slot, ptr(poses), ptr(kind), ptr(prim), ptr(length), ptr(tuv)))
         return dict(poses=poses, kind=kind, prim=prim, length=length, tuv=tuv)
+
+    def postprocess_held(self, n_slots=None, path_interpolation=0.1, smoother=None, max_points=2048):
+        """HybridAStar::SearchPath's post-processing (hybrid_a_star.cpp:260-304) over the field slots 0 .. n_slots-1 of the pipeline's buffer
+        set (pp_planner_postprocess on pp_pipeline_planner()): meaningful for slots whose queries are completed and HELD (polled with
+        release=False); read a query's processed path with get_processed_path_of(ticket)."""
+        n = self.capacity if n_slots is None else int(n_slots)
+        sp = None
+        if smoother is not None:
+            d = dict(step_tolerance=1e-3, max_iterations=2000, learning_rate=0.01, path_weight=0.0, smooth_weight=0.4, voronoi_weight=0.02, collision_weight=0.2,
+                     curvature_weight=0.4, collision_ratio=0.2, max_curvature=1.0 / self.params.min_turning_radius)
+            d.update(smoother)
+            sp = SmootherParams(**d)
+        out = (PostResult * max(n, 1))()
+        check(self.lib.pp_planner_postprocess(self.planner_h, n, C.c_float(path_interpolation), C.byref(sp) if sp is not None else None, int(max_points), out))
+        self._post = list(out)[:n]
+        return self._post
+
+    def get_processed_path_of(self, ticket):
+        slot = self.lib.pp_pipeline_slot_of(self.h, C.c_uint64(int(ticket)))
+        if slot < 0:
+            raise ValueError("ticket is not a completed, held query")
+        r = self._post[slot]
+        n = r.n_points
+        sampled, smoothed = np.empty((n, 3)), np.empty((n, 3))
+        cusp = np.empty(n, dtype=np.uint8)
+        if n:
+            check(self.lib.pp_planner_get_processed_path(self.planner_h, slot, ptr(sampled), ptr(cusp), ptr(smoothed)))
+        return dict(sampled=sampled, cusp=cusp.astype(bool), smoothed=smoothed, status=r.smoothing_status, iterations=r.iterations, length=r.length,
+                    path=smoothed if r.smoothing_status >= 0 else sampled)
 
     def get_expanded_of(self, ticket):
         """expansion sequence (log_expansions=True) of a completed query polled with release=False"""

@@ -470,6 +470,26 @@ def hybrid_batch(world, table, starts, goals, seeds, threads=1, params=None, hea
     return secs, status, cost, nexp
 
 
+def hybrid_batch_paths(world, table, starts, goals, seeds, threads=1, max_poses=256, params=None, heading_alias=True, negative_k_read=True):
+    """hybrid_batch plus the solution paths: returns (seconds, status, cost, n_expanded, poses [n, max_poses, 3], n_poses [n])"""
+    params = params_array() if params is None else params
+    starts = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
+    goals = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 3)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    n = len(starts)
+    status = np.empty(n, dtype=np.int32)
+    cost = np.empty(n)
+    nexp = np.empty(n, dtype=np.int64)
+    poses = np.zeros((n, max_poses, 3))
+    n_poses = np.zeros(n, dtype=np.int32)
+    table = np.ascontiguousarray(table, dtype=np.float64)
+    lib().ppo_hybrid_batch_paths.restype = C.c_double
+    secs = lib().ppo_hybrid_batch_paths(world.h, dptr(params), C.c_int(int(heading_alias)), C.c_int(int(negative_k_read)), dptr(table), C.c_int64(n),
+                                        dptr(starts), dptr(goals), seeds.ctypes.data_as(_u64p), C.c_int(threads), iptr(status), dptr(cost),
+                                        nexp.ctypes.data_as(_i64p), C.c_int(max_poses), dptr(poses), iptr(n_poses))
+    return secs, status, cost, nexp, poses, n_poses
+
+
 def grid_astar(world, init, goal, bidirectional=False, inner_goal_f=None, inner_goal_r=None):
     init = np.array(init, dtype=np.int32)
     goal = np.array(goal, dtype=np.int32)

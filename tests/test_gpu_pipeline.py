@@ -39,6 +39,11 @@ def check_against_oracle(pipe, ticket, r, h, start, goal, seed):
         path = pipe.get_path_of(ticket)
         assert len(path["poses"]) == len(o["path_poses"]) and np.abs(path["poses"] - o["path_poses"]).max() < 1e-5
         assert np.array_equal(path["kind"], o["path_kind"])
+    # the plan as it left the GPU with its completion record (pp_pipeline_get_paths: the ring in pinned host memory)
+    poses, n_poses = pipe.get_paths([ticket], max_poses=512, release=False)
+    assert n_poses[0] == (len(o["path_poses"]) if o["status"] == 0 else 0)
+    if n_poses[0]:
+        assert np.abs(poses[0, :n_poses[0]] - o["path_poses"]).max() < 1e-5
     return o["status"] == 0
 
 
@@ -205,3 +210,77 @@ def test_pipeline_replay_with_queued_launches_and_urgent_slots_recycled_early(mo
     assert pipe.in_flight() == 0
     pipe.close()
     batch.close()
+
+
+def test_paths_longer_than_the_host_ring_and_cut_requests(monkeypatch):
+    """PP_PIPE_PATH_POSES=6: every plan of more than six nodes has its start end fetched from the device records; a request for fewer
+    poses than the path has returns its first poses and the full count."""
+    import pathplanning_amd as pa
+    monkeypatch.setenv("PP_PIPE_PATH_POSES", "6")
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    rng = np.random.RandomState(21)
+    n = 24
+    starts, goals = valid_random_poses(rng, w, n), valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 5
+    pipe = pa.HybridAStarPipeline(val, capacity=32, max_nodes=32768, search_rows=16)
+    pipe.initialize()
+    h = O.Hybrid(w, O.params_array(), table=pipe.nonholo_table())
+    tickets = pipe.submit(starts, goals, seeds)
+    assert len(tickets) == n
+    got = drain(pipe, n, release=False)
+    long_paths = 0
+    for i, t in enumerate(tickets):
+        o = h.search(starts[i], goals[i], int(seeds[i]))
+        poses, n_poses = pipe.get_paths([t], max_poses=512, release=False)
+        want = len(o["path_poses"]) if o["status"] == 0 else 0
+        assert n_poses[0] == want and got[int(t)].status == o["status"]
+        if want:
+            assert np.abs(poses[0, :want] - o["path_poses"]).max() < 1e-5
+            long_paths += want > 6
+            cut, n_cut = pipe.get_paths([t], max_poses=4, release=False)
+            assert n_cut[0] == want and np.abs(cut[0, :min(4, want)] - o["path_poses"][:4]).max() < 1e-5
+    assert long_paths >= 5
+    poses, n_poses = pipe.get_paths(tickets, max_poses=64, release=True)  # the batched form, slots returned
+    assert pipe.free_slots() == 32 and pipe.in_flight() == 0
+    pipe.close()
+
+
+def test_held_slots_post_process_like_the_batch_planner_and_the_buffer_set_refuses_batches():
+    """pp_pipeline_planner() is the handle of the pipeline's buffer set: post-processing its held slots (the rows write the slot's result
+    record on the device too) gives what the batch planner gives for the same queries; batch entry points on it are refused."""
+    import pathplanning_amd as pa
+    PP_ERR_INVALID = -1  # include/pp_hip.h
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    ms.upload_nearest_cells(*O.world_nearest(w))
+    rng = np.random.RandomState(22)
+    n = 12
+    starts, goals = valid_random_poses(rng, w, n), valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 77
+    pipe = pa.HybridAStarPipeline(val, capacity=16, max_nodes=32768, search_rows=8)
+    pipe.initialize()
+    batch = pa.HybridAStarBatch(val, max_batch=n, max_nodes=32768)
+    batch.initialize(pipe.nonholo_table())
+    ref = batch.search_batch(starts, goals, seeds)
+    batch.postprocess(n, path_interpolation=0.8)
+    tickets = pipe.submit(starts, goals, seeds)
+    got = drain(pipe, n, release=False)
+    pipe.postprocess_held(16, path_interpolation=0.8)
+    for i, t in enumerate(tickets):
+        assert got[int(t)].status == ref[i].status and got[int(t)].n_expanded == ref[i].n_expanded
+        a, b = pipe.get_processed_path_of(t), batch.get_processed_path(i)
+        assert a["status"] == b["status"] and len(a["sampled"]) == len(b["sampled"])
+        if len(a["sampled"]):
+            assert np.array_equal(a["sampled"], b["sampled"]) and np.array_equal(a["cusp"], b["cusp"]) and np.array_equal(a["path"], b["path"])
+    # the buffer set is the pipeline's: no batches, no result fetch, no expansion log without log_expansions
+    lib = pipe.lib
+    import ctypes as C
+    from pathplanning_amd._lib import QueryResult, ptr
+    res = (QueryResult * n)()
+    sd = np.ascontiguousarray(seeds)
+    assert lib.pp_planner_search_batch(pipe.planner_h, n, ptr(starts), ptr(goals), ptr(sd), C.cast(res, C.c_void_p)) == PP_ERR_INVALID
+    assert lib.pp_planner_fetch_results(pipe.planner_h, n, C.cast(res, C.c_void_p)) == PP_ERR_INVALID
+    cells = np.zeros((4, 3), dtype=np.int32)
+    assert lib.pp_planner_get_expanded(pipe.planner_h, 0, ptr(cells)) == PP_ERR_INVALID
+    pipe.release(tickets)
+    batch.close()
+    pipe.close()

@@ -20,6 +20,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             v = float(r["Counter_Value"])
             d = raw.setdefault(k, {})
             d[c + "_KB"] = max(d.get(c + "_KB", 0.0), v)
+l2 = {}
+for f in glob.glob("%s/TCC_HIT_MISS/**/*counter_collection.csv" % out, recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] not in ("TCC_HIT_sum", "TCC_MISS_sum"):
+            continue
+        m = re.search(r"(k_[a-z_0-9]+)", r["Kernel_Name"])
+        if not m:
+            continue
+        d = l2.setdefault(m.group(1), {}).setdefault(r.get("Dispatch_Id", "0"), {})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 res = {
     "_note": "HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, from two separate rocprofv3 --pmc passes "
     "(FETCH_SIZE, then WRITE_SIZE) of `bench.py --mode lanes --steps 1 --warmup 0 --streams 1` (4096 queries per launch; 2^26 poses for "
@@ -32,7 +42,16 @@ res = {
 for k, d in raw.items():
     if "FETCH_SIZE_KB" in d and "WRITE_SIZE_KB" in d:
         res[k] = (2 * d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024
+# L2 hit rate per kernel: the dispatch with the most L2 accesses (the full-size launch)
+res["l2_hit"] = {}
+res["_l2_raw"] = {}
+for k, per in l2.items():
+    best = max(per.values(), key=lambda d: d.get("TCC_HIT_sum", 0.0) + d.get("TCC_MISS_sum", 0.0))
+    h, mi = best.get("TCC_HIT_sum", 0.0), best.get("TCC_MISS_sum", 0.0)
+    if h + mi > 0:
+        res["l2_hit"][k] = h / (h + mi)
+        res["_l2_raw"][k] = dict(TCC_HIT_sum=h, TCC_MISS_sum=mi)
 json.dump(res, open(out + "/traffic.json", "w"), indent=1)
 for k, v in res.items():
-    if not k.startswith("_"):
-        print("%-24s %.3e B/launch" % (k, v))
+    if not k.startswith("_") and k != "l2_hit":
+        print("%-24s %.3e B/launch   L2 hit %s" % (k, v, ("%.3f" % res["l2_hit"][k]) if k in res["l2_hit"] else "-"))
