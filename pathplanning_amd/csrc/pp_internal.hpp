@@ -106,7 +106,13 @@ struct WavefrontPublish {
 	// certify (a tie of its fixed-point equation, a run that does not settle) are rebuilt by the ordered kernel, launched behind it on the same stream.
 	int* tilesCtl = nullptr;          // >= 8 ints, zero at allocation (the kernels set them back): tile goal counter, exit counter, handed-over count, ordered goal counter, exit counter
 	int32_t* tilesFallback = nullptr; // [>= number of goals a launch may take] the handed-over goals
-	unsigned long long* tilesStats = nullptr; // optional, 8 words: goals, tile visits, rounds, candidate passes, cells, handed over, wave cycles
+	unsigned long long* tilesStats = nullptr; // optional, 16 words: goals, tile visits, rounds, candidate passes, cells, handed over, wave cycles, ...
+	// optional: the ordered kernel's launch over the handed-over goals goes to this stream, behind `fallbackEvent` recorded on the launching
+	// stream -- so that the launching stream's NEXT tile launch does not wait for it (a dozen goals of 4096 take the ordered kernel 70-110 ms on
+	// a busy chip: a third of a wavefront stream's time when it ran in line).  The caller keeps tilesCtl / tilesFallback / the workspace
+	// untouched until that launch has finished.
+	hipStream_t fallbackStream = nullptr;
+	hipEvent_t fallbackEvent = nullptr;
 	// (set by launch_wavefront for the ordered kernel's launch over the handed-over goals)
 	const int* nGoalsDev = nullptr;   // the launch's number of goals lives on the device
 	int* resetOnExit = nullptr;       // one more word the last workgroup sets back to 0

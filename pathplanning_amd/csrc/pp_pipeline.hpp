@@ -82,6 +82,41 @@ __global__ void __launch_bounds__(256) k_pipe_scatter(int n, const int32_t* __re
 	}
 }
 
+/// Can kernels on the pipeline's other streams start while one stream holds a launch whose workgroups cannot all be placed?  HIP maps streams
+/// onto GPU_MAX_HW_QUEUES hardware queues (default 4; fixed when the runtime starts; no API reports it), and a hardware queue hands out its
+/// packets in order: behind a launch that is still waiting for room for its last workgroups -- a wavefront launch on a chip full of search
+/// waves, the search grid's top-up -- every other stream mapped to that queue waits too (round 2 measured 6.9 k instead of 9.8 k plans/s;
+/// with the persistent grid it is the grid's 50 ms idle time-out that lets the other stream through).  The probe makes exactly that
+/// situation: `k_queue_probe_hog`, far more workgroups than the chip holds, each spinning until every other stream's `k_queue_probe_set`
+/// has run (or 10 ms after the first of them started).  Small kernels on streams that share a queue DO overlap (a probe of eight one-wave
+/// kernels passes with GPU_MAX_HW_QUEUES=2), which is why the probe needs the oversubscribed launch.
+__global__ void __launch_bounds__(64) k_queue_probe_hog(unsigned int* bits, unsigned int want, unsigned long long* start)
+{
+	// (more than half a CU's LDS: one workgroup per CU, so the launch stays oversubscribed -- thousands of workgroups pending -- while
+	// every CU keeps wave slots free for the other streams' kernels)
+	__shared__ volatile unsigned int hold[24 * 1024];
+	hold[threadIdx.x] = 0u;
+	if (threadIdx.x != 0)
+		return;
+	const unsigned long long now = wall_clock64(); // 100 MHz
+	unsigned long long t0 = 0ull;
+	if (__hip_atomic_compare_exchange_strong(start, &t0, now | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+		t0 = now | 1ull;
+	while ((__hip_atomic_load(bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & want) != want) {
+		if (wall_clock64() - t0 > 1000000ull) {
+			// gave up: the setters whose bits are missing could not start beside this launch
+			__hip_atomic_fetch_or(bits + 1, 0x80000000u | (want & ~__hip_atomic_load(bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
+		__builtin_amdgcn_s_sleep(32);
+	}
+}
+__global__ void __launch_bounds__(64) k_queue_probe_set(unsigned int* bits, unsigned int bit)
+{
+	if (threadIdx.x == 0)
+		__hip_atomic_fetch_or(bits, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 constexpr int kPipeSearchStreams = 4;
 constexpr int kPipeWavefrontStreams = 4; // at most; pp_pipeline::nWf of them are used (2 unless PP_PIPE_WF_STREAMS says otherwise)
 
@@ -113,8 +148,17 @@ struct pp_pipeline {
 	std::vector<hipEvent_t> segmentEvents; // spare events
 	long long segmentWaits = 0;            // times a submission had to wait for a launch before reusing its segment (diagnostic)
 	void* wfWorkspace[kPipeWavefrontStreams] = {};
-	int32_t* wfCtl[kPipeWavefrontStreams] = {}; // per wavefront stream: {error flag, goal counter, exit counter, -, then the tile form's eight control words}
-	int32_t* wfFallback[kPipeWavefrontStreams] = {}; // per wavefront stream, [capacity]: the goals the tile form hands to the ordered kernel
+	int32_t* wfCtl[kPipeWavefrontStreams] = {}; // per wavefront stream: {error flag, goal counter, exit counter, ...}
+	// The tile form's control words and hand-over lists, one SET per launch in flight: the ordered kernel's launch over a tile launch's
+	// handed-over goals runs on `fbStream`, behind the tile launch and beside the wavefront stream's next one, and reads its set until it ends
+	// (fbDone[i], recorded behind it; a set is reused only after that).
+	static constexpr int kFbSets = 8;
+	int32_t* fbCtl[kFbSets] = {};  // 16 ints each, zero at allocation (the kernels set them back)
+	int32_t* fbList[kFbSets] = {}; // [capacity]
+	hipEvent_t fbDone[kFbSets] = {}, fbAfterTiles[kFbSets] = {};
+	bool fbUsed[kFbSets] = {};
+	int nextFbSet = 0;
+	hipStream_t fbStream = nullptr;
 	// pinned host
 	PipeDone* done = nullptr;
 	unsigned long long doneMask = 0;
@@ -166,6 +210,14 @@ void free_pipeline(pp_pipeline* P)
 			(void)hipStreamDestroy(s);
 	if (P->ctlStream)
 		(void)hipStreamDestroy(P->ctlStream);
+	if (P->fbStream)
+		(void)hipStreamDestroy(P->fbStream);
+	for (hipEvent_t ev : P->fbDone)
+		if (ev)
+			(void)hipEventDestroy(ev);
+	for (hipEvent_t ev : P->fbAfterTiles)
+		if (ev)
+			(void)hipEventDestroy(ev);
 	if (P->evIngest)
 		(void)hipEventDestroy(P->evIngest);
 	if (P->evCtl)
@@ -182,7 +234,8 @@ void free_pipeline(pp_pipeline* P)
 			if (t.b)
 				(void)hipEventDestroy(t.b);
 		}
-	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->urgent, P->claimed, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfWorkspace[2], P->wfWorkspace[3], P->wfCtl[0], P->wfCtl[1], P->wfCtl[2], P->wfCtl[3], P->wfFallback[0], P->wfFallback[1], P->wfFallback[2], P->wfFallback[3] };
+	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->urgent, P->claimed, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfWorkspace[2], P->wfWorkspace[3], P->wfCtl[0], P->wfCtl[1], P->wfCtl[2], P->wfCtl[3], P->fbCtl[0], P->fbCtl[1], P->fbCtl[2], P->fbCtl[3], P->fbCtl[4], P->fbCtl[5], P->fbCtl[6], P->fbCtl[7],
+		P->fbList[0], P->fbList[1], P->fbList[2], P->fbList[3], P->fbList[4], P->fbList[5], P->fbList[6], P->fbList[7] };
 	for (void* q : dev)
 		if (q)
 			(void)hipFree(q);
@@ -264,6 +317,11 @@ PipeView pipe_view(const pp_pipeline* P)
 int pipe_launch_search(pp_pipeline* P)
 {
 	pp_planner* pl = P->pl;
+	// (the staging ring has 64 entries and the copies are asynchronous: the control stream is drained before an entry can come round again --
+	// every submission synchronises it anyway; this bounds the top-up launches of a long wait between submissions.  Round 3's crash under
+	// rocprofv3 --pmc was an UNBOUNDED stream of such small asynchronous copies issued from the poll path: DESIGN.md 4.10)
+	if ((P->submittedStagePos & 31) == 31)
+		PP_HIP_TRY(hipStreamSynchronize(P->ctlStream));
 	unsigned long long* const src = P->submittedStage + (P->submittedStagePos++ & 63);
 	*src = P->nSubmitted;
 	PP_HIP_TRY(hipMemcpyAsync(&P->ctl->nSubmitted, src, 8, hipMemcpyHostToDevice, P->ctlStream));
@@ -358,11 +416,23 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 			e = hipMalloc((void**)&P->wfCtl[i], 64);
 		if (e == hipSuccess)
 			e = hipMemset(P->wfCtl[i], 0, 64);
-		if (e == hipSuccess)
-			e = hipMalloc((void**)&P->wfFallback[i], (size_t)capacity * 4);
+
 		if (e == hipSuccess)
 			e = wfCus ? masked_stream(&P->wfStream[i], true) : hipStreamCreateWithFlags(&P->wfStream[i], hipStreamNonBlocking);
 	}
+	for (int i = 0; i < pp_pipeline::kFbSets && e == hipSuccess; i++) {
+		e = hipMalloc((void**)&P->fbCtl[i], 64);
+		if (e == hipSuccess)
+			e = hipMemset(P->fbCtl[i], 0, 64);
+		if (e == hipSuccess)
+			e = hipMalloc((void**)&P->fbList[i], (size_t)capacity * 4);
+		if (e == hipSuccess)
+			e = hipEventCreateWithFlags(&P->fbDone[i], hipEventDisableTiming);
+		if (e == hipSuccess)
+			e = hipEventCreateWithFlags(&P->fbAfterTiles[i], hipEventDisableTiming);
+	}
+	if (e == hipSuccess)
+		e = wfCus ? masked_stream(&P->fbStream, true) : hipStreamCreateWithFlags(&P->fbStream, hipStreamNonBlocking);
 	// The wavefront workgroups of a launch in flight stay until its list AND the urgent ring are empty, and launches queue: room on the chip
 	// frees rarely and in bursts.  When it does, the waves that top up the search grid and the scatter kernel of a new submission should get
 	// it before the next wavefront launch's pending workgroups refill the chip: their streams have the highest priority.  A safeguard, not a
@@ -370,7 +440,8 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	// about forty had come in at 12 k before, consistent results, cause not established (profiles/r03_repeat_runs.txt).
 	int prioLow = 0, prioHigh = 0;
 	(void)hipDeviceGetStreamPriorityRange(&prioLow, &prioHigh);
-	if (getenv("PP_PIPE_FLAT_PRIORITY"))
+	const bool flatPriority = getenv("PP_PIPE_FLAT_PRIORITY") != nullptr || prioHigh == prioLow;
+	if (flatPriority)
 		prioHigh = prioLow = 0;
 	for (int i = 0; i < kPipeSearchStreams && e == hipSuccess; i++)
 		e = wfCus ? masked_stream(&P->searchStream[i], false) : hipStreamCreateWithPriority(&P->searchStream[i], hipStreamNonBlocking, prioHigh);
@@ -413,6 +484,73 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		free_pipeline(P);
 		return pph::hip_fail(e, "pipeline allocation");
 	}
+	{
+		// the precondition the pipeline's speed rests on, checked instead of assumed (see k_queue_probe_hog)
+		std::vector<hipStream_t> all;
+		for (int i = 0; i < P->nWf; i++)
+			all.push_back(P->wfStream[i]);
+		for (hipStream_t st : P->searchStream)
+			all.push_back(st);
+		all.push_back(P->fbStream);
+		const size_t nLong = all.size(); // the streams that carry launches which may wait for room
+		all.push_back(P->ctlStream);
+		unsigned int* probe = nullptr; // {setter bits, "the hog gave up" flag, the hog's start stamp (2 words)}
+		e = hipMalloc((void**)&probe, 16);
+		// (a stream gets its hardware queue at its first launch, which takes milliseconds: every stream runs one kernel before the clock matters)
+		for (size_t j = 0; j < all.size() && e == hipSuccess; j++)
+			hipLaunchKernelGGL(k_queue_probe_set, dim3(1), dim3(64), 0, all[j], probe, 1u << j);
+		if (e == hipSuccess)
+			e = hipDeviceSynchronize();
+		int seen[2] = { 1, 1 };
+		int blockedBy = -1;
+		unsigned int blockedMask = 0;
+		for (size_t x = 0; x < nLong && e == hipSuccess && seen[1]; x++) {
+			e = hipMemset(probe, 0, 16);
+			if (e == hipSuccess)
+				e = hipDeviceSynchronize();
+			// (the search and control streams have a higher priority than the wavefront streams: a high-priority launch waiting for room holds
+			// the lower-priority queues back by design -- measured: it does with any number of hardware queues -- so a launch on a search stream
+			// is only asked to let its own class through)
+			const bool xHigh = !flatPriority && x >= (size_t)P->nWf && x < (size_t)P->nWf + kPipeSearchStreams;
+			unsigned int want = 0;
+			for (size_t j = 0; j < all.size(); j++) {
+				const bool jHigh = !flatPriority && ((j >= (size_t)P->nWf && j < (size_t)P->nWf + kPipeSearchStreams) || j + 1 == all.size());
+				if (j != x && (!xHigh || jHigh))
+					want |= 1u << j;
+			}
+			hipLaunchKernelGGL(k_queue_probe_hog, dim3(16384), dim3(64), 0, all[x], probe, want, reinterpret_cast<unsigned long long*>(probe + 2));
+			for (size_t j = 0; j < all.size(); j++)
+				if (j != x)
+					hipLaunchKernelGGL(k_queue_probe_set, dim3(1), dim3(64), 0, all[j], probe, 1u << j);
+			if (e == hipSuccess)
+				e = hipDeviceSynchronize();
+			unsigned int flags[2] = { 0, 0 };
+			if (e == hipSuccess)
+				e = hipMemcpy(flags, probe, 8, hipMemcpyDeviceToHost);
+			seen[1] = flags[1] == 0 ? 1 : 0; // no workgroup of the oversubscribed launch had to give up: every other stream ran beside it
+			if (!seen[1]) {
+				blockedBy = (int)x;
+				blockedMask = flags[1] & 0x7FFFFFFFu;
+			}
+		}
+		if (probe)
+			(void)hipFree(probe);
+		if (e != hipSuccess) {
+			free_pipeline(P);
+			return pph::hip_fail(e, "pipeline queue probe");
+		}
+		const char* allow = getenv("PP_PIPE_ALLOW_SHARED_QUEUES");
+		if (!seen[1] && !(allow && allow[0] == '1')) {
+			free_pipeline(P);
+			set_error("the pipeline's " + std::to_string(all.size()) + " streams do not run side by side (a launch waiting for room on stream " + std::to_string(blockedBy) +
+				" holds back streams 0x" + [&] { char b[16]; snprintf(b, sizeof b, "%x", blockedMask); return std::string(b); }() +
+				"; streams: wavefront, 4 x search, hand-over, control): the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware "
+				"queues (default 4, fixed when the runtime starts) and a wavefront launch queued behind the persistent search grid would wait for the grid's idle "
+				"time-out.  Set GPU_MAX_HW_QUEUES=16 in the environment before the process's first HIP call (pathplanning_amd, bench.py and the tests do), or "
+				"PP_PIPE_ALLOW_SHARED_QUEUES=1 to run anyway");
+			return PP_ERR_INVALID;
+		}
+	}
 	std::memset(P->done, 0, ring * sizeof(PipeDone));
 	std::memset(P->errFlags, 0, 64);
 	P->freeSlots.resize((size_t)capacity);
@@ -454,6 +592,8 @@ int pp_pipeline_destroy(pp_pipeline* P)
 	for (hipStream_t s : P->wfStream)
 		if (s)
 			(void)hipStreamSynchronize(s);
+	if (P->fbStream)
+		(void)hipStreamSynchronize(P->fbStream);
 	for (hipStream_t s : P->searchStream)
 		if (s)
 			(void)hipStreamSynchronize(s);
@@ -539,9 +679,15 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	// ---- inputs into their slots: on the control stream (never busy for long), so the caller's arrays are free when this returns
 	hipStream_t const w = P->wfStream[P->nextWf];
 	int32_t* const wctl = P->wfCtl[P->nextWf];
-	int32_t* const wfb = P->wfFallback[P->nextWf];
+	const int fbSet = P->nextFbSet;
+	P->nextFbSet = (P->nextFbSet + 1) % pp_pipeline::kFbSets;
+	if (P->fbUsed[fbSet])
+		PP_HIP_TRY(hipEventSynchronize(P->fbDone[fbSet])); // (eight launches back: done long ago unless the chip is stuck)
 	int32_t* const werr = P->errFlags + P->nextWf; // (pinned host memory: the kernel's plain store reaches it, poll reads it)
-	void* const wws = P->wfWorkspace[P->nextWf];
+	// (with the tile form the ordered kernel's launches all run on fbStream, one after the other: one workspace; without it they are the
+	// wavefront streams' own launches)
+	const bool tilesOn = pl->map->occBits && pph::wavefront_tiles_enabled() && pph::wavefront_tiles_supported(pl->map->desc.rows, pl->map->desc.cols);
+	void* const wws = P->wfWorkspace[tilesOn ? 0 : P->nextWf];
 	P->nextWf = (P->nextWf + 1) % P->nWf;
 	PP_HIP_TRY(hipMemcpyAsync(listDev, stage, (size_t)k * 4, hipMemcpyHostToDevice, P->ctlStream));
 	pl->args.m = pl->map->view();
@@ -561,8 +707,10 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	pub.goalCounter = wctl + 1; // 0 at creation; the last workgroup of every launch sets it back
 	pub.exitCounter = wctl + 2;
 	pub.claimed = P->claimed;
-	pub.tilesCtl = wctl + 8;
-	pub.tilesFallback = wfb;
+	pub.tilesCtl = P->fbCtl[fbSet];
+	pub.tilesFallback = P->fbList[fbSet];
+	pub.fallbackStream = P->fbStream;
+	pub.fallbackEvent = P->fbAfterTiles[fbSet];
 	if (P->urgentClearance != 0.0f) {
 		pub.urgent = P->urgent;
 		pub.urgentHead = &P->ctl->urgentHead;
@@ -572,6 +720,8 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	PP_HIP_TRY(pph::launch_wavefront(w, pl->args.m, k, nullptr, pl->costFields, wws, pl->wfBytesPerSlot, P->wfBlocks, werr, nullptr, /*tiledOut=*/true, /*goalPoses=*/pl->dGoals,
 		/*countersZeroed=*/true, nullptr, nullptr, nullptr, nullptr, pub));
 	timed_done(P, w, tm);
+	PP_HIP_TRY(hipEventRecord(P->fbDone[fbSet], P->fbStream));
+	P->fbUsed[fbSet] = true;
 	PP_HIP_TRY(hipEventRecord(seg.done, w));
 	P->segmentEvents.pop_back();
 	P->segments.push_back(seg);

@@ -517,6 +517,12 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 			bandLo = bAbs & ~3ll;           // every band below the lowest one was empty: the window moves up (multiple of 4)
 			loadedTop = ((bAbs >> 2) << 2) | 3; // the group's bands inside the window are empty now
 		}
+		// (the bound of the outside part is rebuilt from here: spill() lowers it for every entry the loop below pushes out of a full buffer
+		// -- those go back into bands at or below `loadedTop` when the spill buffer fills up, where the band-boundary term further down does
+		// not see them.  Without this a later, worse entry could enter the buffer ahead of them: found on a 44 597-expansion query of the
+		// full-size batch, whose expansion order left the oracle's at expansion 41 196; tests/test_gpu_fullsize.py)
+		lowK = ~0ull;
+		lowS = ~0u;
 		// heap entries that come before the buffer's last entry (or, with an empty buffer, the heap's best) move in
 		while (heapSize > 0 && (frontCount == 0 || key_before(heapTop.ckey, heapTop.nseq, lane_read64(front.ckey, frontCount - 1), lane_read(front.nseq, frontCount - 1)))) {
 			__syncthreads();
@@ -529,8 +535,10 @@ __global__ void __launch_bounds__(64, PP_SEARCH_WAVES_PER_SIMD) k_hybrid_search(
 		}
 		// lower bound of what is outside now: the heap's best, the start of the first band that was not loaded, the spill
 		// buffer
-		lowK = heapSize > 0 ? heapTop.ckey : ~0ull;
-		lowS = heapSize > 0 ? heapTop.nseq : ~0u;
+		if (heapSize > 0 && key_before(heapTop.ckey, heapTop.nseq, lowK, lowS)) {
+			lowK = heapTop.ckey;
+			lowS = heapTop.nseq;
+		}
 		{
 			const unsigned long long bk = cost_key((double)(loadedTop + 1) / bandInvW);
 			if (bk < lowK || (bk == lowK && 0u < lowS)) {

@@ -1402,7 +1402,18 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 		fb.agentPoseLoads = pub.claimed != nullptr;
 		fb.tilesCtl = nullptr;
 		const int fgrid = nSlots < 16 ? (nSlots < nGoals ? nSlots : nGoals) : (nGoals < 16 ? nGoals : 16);
-		hipLaunchKernelGGL(k_wavefront<false>, dim3(fgrid), dim3(WF_T), 0, s, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
+		hipStream_t fs = s;
+		if (pub.fallbackStream && pub.fallbackEvent) {
+			e = hipEventRecord(pub.fallbackEvent, s);
+			if (e == hipSuccess)
+				e = hipStreamWaitEvent(pub.fallbackStream, pub.fallbackEvent, 0);
+			if (e != hipSuccess)
+				return e;
+			fs = pub.fallbackStream;
+		}
+		fb.fallbackStream = nullptr;
+		fb.fallbackEvent = nullptr;
+		hipLaunchKernelGGL(k_wavefront<false>, dim3(fgrid), dim3(WF_T), 0, fs, m, nGoals, goalCellsDev, costDev, workspaceDev, workspaceBytesPerSlot, fcap, gcap, errorFlagDev,
 			(unsigned long long*)nullptr, fb.goalCounter, tiledOut ? 1 : 0, goalPosesDev, orderStartsDev, (int32_t*)nullptr, (int*)nullptr, orderStartsDev ? orderKeysDev : nullptr, fb);
 		e = hipGetLastError();
 		if (e != hipSuccess)

@@ -153,8 +153,30 @@ static void TestPipeline()
 	std::printf("pipeline: %d queries through 16 slots (%d solved), statuses and costs equal to SearchPath's\n", n, solved);
 }
 
-int main()
+// The pipeline in a process whose environment may not give the HIP runtime enough hardware queues (include/pp_hip.h, pp_pipeline_create): it
+// must either run at full speed -- the 40-query test above passes -- or refuse loudly, naming GPU_MAX_HW_QUEUES; never limp along in silence.
+static int TestQueuePrecondition()
 {
+	std::array<Pose2d, 2> bounds = { Pose2d(-10, -10, -M_PI), Pose2d(10, 10, M_PI) };
+	Ref<StateSpaceSE2> stateSpace = makeRef<StateSpaceSE2>(bounds);
+	Ref<OccupancyMap> map = makeRef<OccupancyMap>(0.1f);
+	Ref<StateValidatorOccupancyMap> validator = makeRef<StateValidatorOccupancyMap>(stateSpace, map);
+	{
+		HybridAStarPipeline pipe(HybridAStar::SearchParameters(), /*capacity=*/16, /*maxNodes=*/32768, /*searchRows=*/8);
+		if (!pipe.Initialize(validator)) {
+			std::printf("pipeline refused: %s\n", pp_last_error());
+			return 0;
+		}
+	} // (destroyed: the test below makes its own, and two pipelines at once need twice the hardware queues)
+	TestPipeline();
+	std::printf("pipeline accepted and ran\n");
+	return 0;
+}
+
+int main(int argc, char** argv)
+{
+	if (argc > 1 && std::string(argv[1]) == "--queues")
+		return TestQueuePrecondition();
 	TestPipeline();
 	TestHybridAStar();
 	TestRRT();

@@ -108,6 +108,22 @@ def test_full_size_batch_properties():
         assert np.array_equal(planner.get_expanded_of(q), r["expanded"])
         if r["status"] == 0:
             assert abs(res[q].cost - r["cost"]) < 1e-5
+    # ---- the hard cases, at full size: every query that exhausts the lattice (status -1 after ~65 k expansions: the ones the hand-over and
+    # the pipeline's urgent ring exist for) and the 16 longest successes -- the whole expansion sequence against the oracle (~1 s of CPU each)
+    status = np.array([r.status for r in res])
+    failures = [int(q) for q in np.flatnonzero((status != 0) & (nexp > 20000))]
+    longest = [int(q) for q in np.argsort(np.where(status == 0, nexp, -1))[-16:]]
+    assert 4 <= len(failures) <= 64 and min(nexp[longest]) > 10000
+    h.set_max_expansions(1 << 30)
+    for q in failures + longest:
+        r = h.search(starts[q], goals[q], int(seeds[q]))
+        assert res[q].status == r["status"] and res[q].n_expanded == len(r["expanded"]) and res[q].n_nodes == r["n_nodes"], q
+        assert np.array_equal(planner.get_expanded_of(q), r["expanded"]), q
+        assert res[q].n_rng_draws == r["n_rng_draws"] and res[q].n_rs_attempts == r["n_rs_attempts"], q
+        if r["status"] == 0:
+            assert abs(res[q].cost - r["cost"]) < 1e-5
+            path = planner.get_path_of(q)
+            assert len(path["poses"]) == len(r["path_poses"]) and np.abs(path["poses"] - r["path_poses"]).max() < 1e-5
 
 
 def test_own_table_on_the_benchmark_map():

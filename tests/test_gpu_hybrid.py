@@ -225,6 +225,31 @@ def test_config5_4096_map_queries():
     assert compare(planner, res, h, starts, goals, seeds) >= 2
 
 
+def test_config5_4096_map_reference_order_fields_16_queries():
+    """Config 5 with the fields the drop-in builds by default: 96 rectangle outlines rasterised through the product, GVD::Update in
+    REFERENCE ORDER (a non-zero path-cost grid: the Voronoi term of every edge cost is live), 16 random queries -- against the oracle planning
+    on ITS OWN brushfire's grids.  Status, expansion sequence, counters, cost and path of every query."""
+    import pathplanning_amd as pa
+    from pathplanning_amd import synthetic
+    ctx = pa.Context(0)
+    m, info = synthetic.make_map_product(ctx, 4096, 96, 11, reference_order=True)
+    assert float(m["path_cost"].max()) > 0.0
+    w = O.synthetic_world(4096, 96, 11)  # the same outlines through the oracle's own rasteriser and brushfire
+    assert np.array_equal(w.occ() >= 0, m["occ"] >= 0)
+    ms, val = synthetic.upload(ctx, m)
+    n = 16
+    # (random poses: off the lattice lines; connected to the bulk of the free space for the robot, so that no query has to exhaust the
+    # 1.2 M cells of this map's lattice -- the planner's node buffers here hold 262 144)
+    reach = synthetic.reachable_mask(val, m)
+    starts = synthetic.sample_valid_poses(val, m, n, seed=12, reachable=reach)
+    goals = synthetic.sample_valid_poses(val, m, n, seed=13, reachable=reach)
+    seeds = np.arange(n, dtype=np.uint64) + 31
+    planner, res, h = run_pair(w, ms, val, {}, starts, goals, seeds, max_nodes=262144)
+    assert all(r.status in (0, -1) for r in res), [r.status for r in res]
+    h.set_max_expansions(262144)
+    assert compare(planner, res, h, starts, goals, seeds) >= 8
+
+
 def test_long_queries_are_handed_over_to_the_one_query_kernel(monkeypatch):
     """Rows kernel in three stages: queries beyond 40 expansions are set aside (open list flushed into the heap, scalars
     in a SuspendRec) and continued by a second pass of the rows kernel in the same slot; beyond 150 expansions the

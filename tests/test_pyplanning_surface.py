@@ -142,6 +142,32 @@ def test_cpp_plugin_mirror_of_reference_tests():
     assert "plugin tests ok" in out.stdout
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("queues", [None, "2", "16"])
+def test_pipeline_states_its_hardware_queue_precondition(queues):
+    """A C++ host that did not set GPU_MAX_HW_QUEUES (or set it too low) before the HIP runtime started: pp_pipeline_create either finds that
+    its streams do run side by side and the pipeline works, or returns an error that names the variable -- it does not run ten times
+    slower in silence (include/pp_hip.h)."""
+    import os
+    import subprocess
+    from pathplanning_amd import build
+    exe = build.build_plugin_test(verbose=False)
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    env.pop("PP_PIPE_ALLOW_SHARED_QUEUES", None)
+    if queues is not None:
+        env["GPU_MAX_HW_QUEUES"] = queues
+    out = subprocess.run([exe, "--queues"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    ran = "pipeline accepted and ran" in out.stdout
+    refused = "pipeline refused" in out.stdout and "GPU_MAX_HW_QUEUES" in out.stdout
+    assert ran != refused, out.stdout
+    if queues == "16":
+        assert ran, out.stdout
+    if queues == "2":
+        assert refused, out.stdout
+
+
 def test_path_value_types_on_the_host(nav):
     """PathSE2 / PathConstantSteer / KinematicBicycleModel / Pose2d composition are plain host arithmetic in the mirror
     (paths/path_se2.cpp, path_constant_steer.cpp, models/kinematic_bicycle_model.cpp, geometry/2dplane.h:47-79)."""
