@@ -25,7 +25,6 @@ using namespace pph;
 ppd::MapView pp_map::view() const
 {
 	ppd::MapView v;
-	int nWordRows_unused = 0;
 	v.rows = desc.rows;
 	v.cols = desc.cols;
 	v.res = desc.resolution;
@@ -46,8 +45,6 @@ ppd::MapView pp_map::view() const
 	v.pathcost = pathcost;
 	v.occ8 = occ8;
 	v.validBits = validBits;
-	v.occBits = occBits;
-	pph::occ_bits_dims(desc.rows, desc.cols, v.occWpr, nWordRows_unused);
 	return v;
 }
 
@@ -741,6 +738,7 @@ int pp_obstacle_heuristic_dev(pp_map* map, int32_t n_goals, const double* goal_x
 	if (tiles) {
 		pub.tilesCtl = dtiles.as<int>();
 		pub.tilesFallback = dtiles.as<int32_t>() + 16;
+		pub.occBits = map->occBits;
 	}
 	PP_HIP_TRY(launch_wavefront(s, map->view(), n_goals, dc.as<int32_t>(), cost_dev, ws.p, wsb, nSlots, derr.as<int32_t>(), nullptr, false, nullptr, false, nullptr, nullptr, nullptr,
 		nullptr, pub));
@@ -784,6 +782,7 @@ int pp_obstacle_heuristic_tiles_stats(pp_map* map, int32_t n_goals, const double
 	pub.tilesCtl = dtiles.as<int>();
 	pub.tilesFallback = dtiles.as<int32_t>() + 16;
 	pub.tilesStats = dstats.as<unsigned long long>();
+	pub.occBits = map->occBits;
 	PP_HIP_TRY(hipEventRecord(map->ctx->ev0, s));
 	PP_HIP_TRY(launch_wavefront(s, map->view(), n_goals, dc.as<int32_t>(), cost_dev, ws.p, wsb, nSlots, derr.as<int32_t>(), nullptr, false, nullptr, false, nullptr, nullptr, nullptr,
 		nullptr, pub));

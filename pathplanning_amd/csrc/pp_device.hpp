@@ -65,8 +65,6 @@ struct MapView {
 	const float* pathcost;  // GVD::PathCostMap
 	const uint8_t* occ8;    // 1 = occupied
 	const uint32_t* validBits; // bit (row * cols + col): dist >= minSafeRadius, rebuilt when either changes (128 KiB at 1024^2)
-	const uint64_t* occBits;   // occupancy as bits for the tile form of the wavefront (pp_wavefront_tiles.hip): word (row + 1) * occWpr + col / 64 + 1,
-	int occWpr;                // bit col % 64; one word of padding on every side, everything outside the map occupied; rebuilt with occ8
 };
 
 /// a / b for a divisor whose correctly rounded reciprocal y = 1.0 / b is known (resolutions: wave-uniform kernel

@@ -104,6 +104,8 @@ struct WavefrontPublish {
 	int* claimed = nullptr;
 	// The tile form of the wavefront (pp_wavefront_tiles.hip) builds the fields when the caller provides its control words; the goals it cannot
 	// certify (a tie of its fixed-point equation, a run that does not settle) are rebuilt by the ordered kernel, launched behind it on the same stream.
+	const uint64_t* occBits = nullptr; // pp_map::occBits: the occupancy as padded bit rows (word (row + 1) * wpr + col / 64 + 1, bit col % 64; one word of padding on
+	                                   // every side, everything outside the map occupied; occ_bits_dims), rebuilt with occ8
 	int* tilesCtl = nullptr;          // >= 8 ints, zero at allocation (the kernels set them back): tile goal counter, exit counter, handed-over count, ordered goal counter, exit counter
 	int32_t* tilesFallback = nullptr; // [>= number of goals a launch may take] the handed-over goals
 	unsigned long long* tilesStats = nullptr; // optional, 16 words: goals, tile visits, rounds, candidate passes, cells, handed over, wave cycles, ...
@@ -118,7 +120,7 @@ struct WavefrontPublish {
 	int* resetOnExit = nullptr;       // one more word the last workgroup sets back to 0
 	bool agentPoseLoads = false;      // read goal poses with agent-scope loads although no claim words are in use
 };
-/// occupancy bits of the tile form (MapView::occBits): words per row and rows of the padded word grid
+/// occupancy bits of the tile form (WavefrontPublish::occBits): words per row and rows of the padded word grid
 void occ_bits_dims(int rows, int cols, int& wpr, int& nWordRows);
 hipError_t launch_occ_bits(hipStream_t s, const uint8_t* occ8, int rows, int cols, uint64_t* bits);
 bool wavefront_tiles_supported(int rows, int cols);
@@ -168,7 +170,7 @@ struct pp_map {
 	float* pathcost = nullptr;
 	uint8_t* occ8 = nullptr;
 	uint32_t* validBits = nullptr; // one bit per cell: dist >= minSafeRadius
-	uint64_t* occBits = nullptr;   // occupancy as padded bit rows (MapView::occBits), rebuilt whenever occ8 is
+	uint64_t* occBits = nullptr;   // occupancy as padded bit rows (WavefrontPublish::occBits), rebuilt whenever occ8 is
 	// map authoring / field construction on the device (pp_gvd.hip)
 	int32_t* occ32 = nullptr;      // occupancy ids as the reference holds them (-1 free)
 	uint32_t* obstLabel[2] = { nullptr, nullptr }; // nearest obstacle cell (row << 16 | col), ping-pong

@@ -707,6 +707,7 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	pub.goalCounter = wctl + 1; // 0 at creation; the last workgroup of every launch sets it back
 	pub.exitCounter = wctl + 2;
 	pub.claimed = P->claimed;
+	pub.occBits = pl->map->occBits;
 	pub.tilesCtl = P->fbCtl[fbSet];
 	pub.tilesFallback = P->fbList[fbSet];
 	pub.fallbackStream = P->fbStream;

@@ -1754,6 +1754,7 @@ int pp_planner_search_batch_dev(pp_planner* planner, int32_t n_queries, const do
 		pph::WavefrontPublish pub;
 		pub.tilesCtl = planner->tilesCtl;
 		pub.tilesFallback = planner->tilesFallback;
+		pub.occBits = planner->map->occBits;
 		PP_HIP_TRY(pph::launch_wavefront(s, m, n_queries, nullptr, planner->costFields, planner->wfWorkspace, planner->wfBytesPerSlot, planner->wfSlots,
 			planner->wfError, nullptr, /*tiledOut=*/true, /*goalPoses=*/goals_dev, /*countersZeroed=*/true, ordered ? starts_dev : nullptr, ordered ? planner->order : nullptr,
 			planner->wfError + 6, planner->orderKeys, pub));

@@ -1384,7 +1384,7 @@ hipError_t launch_wavefront(hipStream_t s, const MapView& m, int nGoals, const i
 		return hipSuccess;
 	uint32_t fcap, gcap;
 	wf_caps(m.rows, m.cols, fcap, gcap);
-	if (pub.tilesCtl && pub.tilesFallback && !profDev && m.occBits && wavefront_tiles_enabled() && wavefront_tiles_supported(m.rows, m.cols)) {
+	if (pub.tilesCtl && pub.tilesFallback && !profDev && pub.occBits && wavefront_tiles_enabled() && wavefront_tiles_supported(m.rows, m.cols)) {
 		// The tile form (pp_wavefront_tiles.hip) builds the fields; behind it, on the same stream, the ordered kernel takes the goals it handed
 		// over (their number is a device word: normally 0, and its few workgroups leave at once), then the hand-out order if the planner wants one.
 		hipError_t e = launch_wavefront_tiles(s, m, nGoals, goalCellsDev, costDev, tiledOut, goalPosesDev, orderStartsDev, orderKeysDev, pub);

@@ -185,8 +185,8 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
 	const int64_t cells = (int64_t)rows * cols;
 	const int64_t fieldElems = A.tiledOut ? (int64_t)field_tiled_elems(rows, cols) : cells;
-	const uint64_t* const occW = m.occBits;
-	const int wpr = m.occWpr;
+	const uint64_t* const occW = A.pub.occBits;
+	const int wpr = (cols + 63) / 64 + 2; // (occ_bits_dims)
 	auto out_index = [&](int r, int c) -> size_t { return A.tiledOut ? field_tiled_index(cols, r, c) : (size_t)r * cols + c; };
 
 	int pendingSlot = -1;
