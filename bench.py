@@ -60,7 +60,7 @@ def main():
                     help="pipeline (default): the library's streaming pipeline (pp_pipeline_*): one persistent search grid fed by the wavefront kernel through a "
                          "device-side queue, field slots recycled; lanes: round 2's scheduling, --streams batch planners refilled by this script")
     ap.add_argument("--capacity", type=int, default=0, help="--mode pipeline: queries in flight (field slots); 0 = 6 steps' worth")
-    ap.add_argument("--pipe-rows", type=int, default=3072, help="--mode pipeline: rows of the persistent search grid")
+    ap.add_argument("--pipe-rows", type=int, default=4096, help="--mode pipeline: rows of the persistent search grid")
     ap.add_argument("--map-source", choices=("product", "synthetic"), default="product",
                     help="product: outlines -> pp_map_set_cells -> pp_map_update_gvd_ex(REFERENCE_ORDER) (the library's own map pipeline); synthetic: numpy / scipy generator of rounds 1-2")
     ap.add_argument("--submit-chunk", type=int, default=4096, help="--mode pipeline: queries per submission (= per wavefront launch)")

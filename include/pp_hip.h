@@ -347,7 +347,7 @@ int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_checke
 /* ---- streaming form of HybridAStar::SearchPath's search stage (algo/hybrid_a_star.cpp:237-257) ------------------------------
  * One pipeline per GPU: `capacity` queries in flight (a field slot each: the obstacle-heuristic field of its goal, start / goal /
  * seed, path and Reeds-Shepp log), ObstaclesHeuristic::Update by the wavefront kernel, which hands every finished field to ONE
- * persistent search grid of `search_rows` rows (0 = 3072) through a device-side queue; a row takes the next ready query as soon as
+ * persistent search grid of `search_rows` rows (0 = 4096) through a device-side queue; a row takes the next ready query as soon as
  * its own ends, slots are recycled as results are polled.  No batch boundary: a query that exhausts the lattice (~1 s) holds one
  * row, not a batch's 17 GB of fields.  Results per query are exactly those of pp_planner_search_batch (same kernels' device code).
  * log_expansions != 0 keeps the expansion log per slot (parity tests; 4 B x max_nodes_per_query per slot).

@@ -168,6 +168,7 @@ struct pp_pipeline {
 	int32_t* errFlags = nullptr; // [streams] the wavefront kernels' error flags, in pinned host memory: written by the device, read by poll
 	double* pathHost = nullptr;  // [capacity][pathHostCap][3]: the poses of every finished query's solution path, goal first, written by the row that finished it
 	int pathHostCap = 192;       // poses per slot in that ring (longer paths: the rest is fetched from the device records); PP_PIPE_PATH_POSES
+	unsigned long long lingerTicks = 0; // PP_PIPE_LINGER_MS: how long an idle search wave stays after everything submitted has been claimed (0: it leaves at once)
 	bool dead = false;           // a submission failed half way: the pipeline's accounting is no longer trustworthy (every later call fails)
 	unsigned long long lastTail = 0, lastHead = 0; // the ready queue's counters as the latest completion record saw them
 	// streams
@@ -307,6 +308,7 @@ PipeView pipe_view(const pp_pipeline* P)
 	v.doneMask = P->doneMask;
 	v.waveAlive = P->waveAlive;
 	v.idleTicks = P->idleTicks;
+	v.lingerTicks = P->lingerTicks;
 	v.pathHost = P->pathHost;
 	v.pathHostCap = P->pathHostCap;
 	return v;
@@ -356,7 +358,7 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	auto* P = new pp_pipeline();
 	P->capacity = capacity;
 	if (search_rows == 0)
-		search_rows = 3072; // measured optimum on MI355X with the tile form of the wavefront (profiles/r04_pipeline_sweeps.txt; 2560 with the ordered kernel, round 3)
+		search_rows = 4096; // measured optimum on MI355X with the tile form of the wavefront (profiles/r04_pipeline_sweeps.txt; 2560 with the ordered kernel, round 3)
 	if (int rc = create_planner(map, params, capacity, max_nodes_per_query, search_rows, log_expansions ? PlannerUse::PipelineLogged : PlannerUse::Pipeline, &P->pl)) {
 		delete P;
 		return rc;
@@ -569,6 +571,10 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 			const long x = strtol(b, nullptr, 10);
 			if (x >= 1 && x < P->wfBlocks)
 				P->wfBlocks = (int)x;
+		}
+		if (const char* lg = getenv("PP_PIPE_LINGER_MS")) {
+			const double ms = strtod(lg, nullptr);
+			P->lingerTicks = (unsigned long long)((ms < 0 ? 0 : (ms > 1000 ? 1000 : ms)) * 250.0);
 		}
 		const char* v = getenv("PP_PIPE_IDLE_MS"); // how long a wave waits for work that does not come before it leaves on its own
 		if (v && *v) {

@@ -1174,6 +1174,7 @@ struct PipeView {
 	PipeDone* done = nullptr;
 	unsigned long long doneMask = 0;
 	int* waveAlive = nullptr;         // [waves] 1 while a wave of some launch owns that wave index (and with it the rows' buffers)
+	unsigned long long lingerTicks = 0; // loop passes an idle wave stays although every submitted query has been claimed: the next submission is usually on its way
 	double* pathHost = nullptr;       // pinned host memory, [capacity][pathHostCap][3]: the solution path's poses, goal first (write_path)
 	int pathHostCap = 0;
 	unsigned long long idleTicks = 0; // loop passes (~4 us each: a sleep and three polls) a wave waits without work before it leaves on its own

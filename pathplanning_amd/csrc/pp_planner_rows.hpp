@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				const unsigned long long head = __hip_atomic_load(&pipe.ctl->readyHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				const int stop = __hip_atomic_load(&pipe.ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				const bool timedOut = (unsigned long long)idleIters > pipe.idleTicks;
-				if (stop || head >= sub || timedOut) {
+				if (stop || (head >= sub && (unsigned long long)idleIters >= pipe.lingerTicks) || timedOut) {
 					// the wave index goes back first, THEN the submission count is read again: a top-up launch that found this index
 					// still owned was started after its submission count was written, so one of the two sees the other
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -52,7 +52,8 @@ constexpr uint32_t kInfBits = 0x7F800000u;
 #define PP_WF_TILES_PRIO_DEFAULT 1 // as the search rows' (PP_ROWS_PRIO): measured 22.9-23.6 k plans/s against 19.3-22.4 k at 0 and 19.4 k at 2 (gpurun_out/r4_sweep_prio.txt)
 #endif
 #ifndef PP_WF_TILE_WIDTH_DEFAULT
-#define PP_WF_TILE_WIDTH_DEFAULT 64
+#define PP_WF_TILE_WIDTH_DEFAULT 32 // measured in the pipeline (gpurun_out/r4_sweep_tw32*.txt): 26.3-26.9 k plans/s at 4096 search rows against 22.8 k with 64-column tiles -- eight waves
+                                   // fit a pack's 93 KB instead of five; alone the two widths are equal (80-83 ms per 4096 goals)
 #endif
 
 __device__ __forceinline__ void wave_sync()
@@ -414,31 +415,44 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 					stRounds++;
 					TILE_STAMP(1) // a round's masks
 					const float kNext2 = (float)(k + 2);
+					// A lane settles TWO of its row's candidates per pass: the sixteen LDS reads of both are in flight together, so a row that the
+					// front crosses at a flat angle (two or three candidates) costs one latency chain, not two or three.  (A candidate next to the
+					// other one may read it before or after its cost is written: either way a cost of bucket k+1 or later, never the minimum.)
+					auto settle = [&](Mask bit, uint32_t w, uint32_t e, uint32_t n, uint32_t s, uint32_t nw, uint32_t ne, uint32_t sw, uint32_t se) -> float {
+						// costs are non-negative floats (+inf = none): their bit patterns order like the values, so the minima are integer
+						// minima (v_min3_u32; a float minimum first quiets its operands: six more instructions per candidate)
+						const uint32_t minS = min(min(w, e), min(n, s));
+						uint32_t minD = (aNW & bit) ? nw : kInfBits;
+						minD = min(minD, (aNE & bit) ? ne : kInfBits);
+						minD = min(minD, (aSW & bit) ? sw : kInfBits);
+						minD = min(minD, (aSE & bit) ? se : kInfBits);
+						flagged |= minS == minD; // a straight and a diagonal neighbour tie for the minimum: the pop order would decide
+						return minS <= minD ? __uint_as_float(minS) + 1.0f : __uint_as_float(minD) + kDiag; // float pathCost = transitionCost + m_cost[cell], heuristics.cpp:134-135
+					};
 					while (__ballot(cand != 0)) {
 						stPasses++;
 						if (cand != 0) {
-							const int j = (int)__builtin_ctzll((uint64_t)cand);
-							const Mask bit = (Mask)1 << j;
-							cand &= (Mask)~bit;
-							const int a = (lane + 1) * LS + j + 1;
-							// costs are non-negative floats (+inf = none): their bit patterns order like the values, so the minima are integer
-							// minima (v_min3_u32; a float minimum first quiets its operands: six more instructions per candidate)
-							const uint32_t w = Lu[a - 1], e = Lu[a + 1], n = Lu[a - LS], s = Lu[a + LS];
-							const uint32_t nw = Lu[a - LS - 1], ne = Lu[a - LS + 1], sw = Lu[a + LS - 1], se = Lu[a + LS + 1];
-							const uint32_t minS = min(min(w, e), min(n, s));
-							uint32_t minD = (aNW & bit) ? nw : kInfBits;
-							minD = min(minD, (aNE & bit) ? ne : kInfBits);
-							minD = min(minD, (aSW & bit) ? sw : kInfBits);
-							minD = min(minD, (aSE & bit) ? se : kInfBits);
-							flagged |= minS == minD; // a straight and a diagonal neighbour tie for the minimum: the pop order would decide
-							const float v = minS <= minD ? __uint_as_float(minS) + 1.0f : __uint_as_float(minD) + kDiag; // float pathCost = transitionCost + m_cost[cell], heuristics.cpp:134-135
-							L[a] = v;
-							closed |= bit;
-							if (v < kNext2)
-								nx1 |= bit;
-							else
-								nx2 |= bit;
-							stCells++;
+							const int j0 = (int)__builtin_ctzll((uint64_t)cand);
+							const Mask bit0 = (Mask)1 << j0;
+							cand &= (Mask)~bit0;
+							const bool two = cand != 0;
+							const int j1 = two ? (int)__builtin_ctzll((uint64_t)cand) : j0;
+							const Mask bit1 = (Mask)1 << j1;
+							cand &= (Mask)~bit1;
+							const int a0 = (lane + 1) * LS + j0 + 1, a1 = (lane + 1) * LS + j1 + 1;
+							const uint32_t w0 = Lu[a0 - 1], e0 = Lu[a0 + 1], n0 = Lu[a0 - LS], s0 = Lu[a0 + LS];
+							const uint32_t nw0 = Lu[a0 - LS - 1], ne0 = Lu[a0 - LS + 1], sw0 = Lu[a0 + LS - 1], se0 = Lu[a0 + LS + 1];
+							const uint32_t w1 = Lu[a1 - 1], e1 = Lu[a1 + 1], n1 = Lu[a1 - LS], s1 = Lu[a1 + LS];
+							const uint32_t nw1 = Lu[a1 - LS - 1], ne1 = Lu[a1 - LS + 1], sw1 = Lu[a1 + LS - 1], se1 = Lu[a1 + LS + 1];
+							const float v0 = settle(bit0, w0, e0, n0, s0, nw0, ne0, sw0, se0);
+							const float v1 = settle(bit1, w1, e1, n1, s1, nw1, ne1, sw1, se1);
+							L[a0] = v0;
+							if (two)
+								L[a1] = v1;
+							closed |= bit0 | bit1;
+							nx1 |= (v0 < kNext2 ? bit0 : (Mask)0) | (v1 < kNext2 ? bit1 : (Mask)0);
+							nx2 |= (v0 < kNext2 ? (Mask)0 : bit0) | (v1 < kNext2 ? (Mask)0 : bit1);
+							stCells += two ? 2 : 1;
 						}
 						wave_sync();
 					}

@@ -1,10 +1,10 @@
-// pybind11 module `pyplanning`: the reference's Python surface (interfaces/python/src/pyplanning.cpp)
-// for the hot path, same class / method names, backed by libpphip.so through planner_hip.hpp.
-// Bound here: initialize, Status, Point2d, Pose2d, GridCellPosition, Direction, StateSpaceSE2,
-// OccupancyMap (+ set_grids), StateValidatorSE2Base, StateValidatorOccupancyMap, HybridAStarSearchParameters,
-// HybridAStarStats, PathPlannerSE2Base, HybridAStar; new surface: search_batch, RRT / RRTStar (the reference
-// does not bind RRT).  Map authoring classes (shapes, ObstacleListOccupancyMap, GVD) and paths are not part
-// of the hot path and are not bound.
+// pybind11 module `pyplanning`: the reference's Python surface (interfaces/python/src/pyplanning.cpp), same class / method names, backed
+// by libpphip.so through planner_hip.hpp.  Every name the reference's module binds is bound here (tests/golden/pyplanning_bound_names.json,
+// tests/test_pyplanning_surface.py): initialize, Status, Point2d, Pose2d, GridCellPosition, Steer, Direction, the path value types and
+// connections, KinematicBicycleModel, StateSpaceSE2, OccupancyMap (+ set_grids), ObstacleListOccupancyMap, Obstacle and the shapes, GVD,
+// StateValidatorSE2Base / SE2Free / OccupancyMap, HybridAStarSearchParameters / SmootherParameters / Stats, PathPlannerSE2Base, HybridAStar,
+// the N2 heuristics / propagators / planners.  New surface next to it: search_batch, GridAStarBatch, RRT / RRTStar (the reference does not
+// bind RRT).
 #include <pybind11/functional.h>
 #include <pybind11/numpy.h>
 #include <pybind11/operators.h>

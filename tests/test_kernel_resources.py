@@ -39,11 +39,11 @@ def test_scratch_and_spills_do_not_regress():
         k = res[name]
         assert k["scratch_bytes_per_lane"] <= scratch, (name, k)
         assert k["vgpr_spill"] <= spills, (name, k)
-    # the tile form of the wavefront (all instantiations): no scratch at all, and few enough registers for five waves per SIMD (96)
+    # the tile form of the wavefront (all instantiations): no scratch at all, and few enough registers for two waves beside a 256-register search wave on a SIMD (112)
     tiles = [k for k in kernel_resources.resources(lib) if k["kernel"].startswith("k_wavefront_tiles")]
     assert len(tiles) >= 2
     for k in tiles:
-        assert k["scratch_bytes_per_lane"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 96, k
+        assert k["scratch_bytes_per_lane"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 112, k
     # the wavefront kernel must keep two workgroups of eight waves per CU: <= 128 VGPRs, <= 80 KiB LDS
     assert res["k_wavefront<false>"]["vgpr"] <= 128 and res["k_wavefront<false>"]["lds_bytes"] <= 80 * 1024
 
