@@ -424,9 +424,12 @@ def main():
         se_bytes = n_children * CHILD_BYTES
     wf_gbs = wf_bytes / (wf * 1e-3) / 1e9
     se_gbs = se_bytes / (se * 1e-3) / 1e9
+    # (the obstacle-heuristic fields are built by the tile form of the wavefront, k_wavefront_tiles, unless PP_WF_TILES=0 sends every goal through
+    # the ordered kernel k_wavefront; the key of this entry stays "k_wavefront" for the earlier rounds' records)
+    WF_KERNEL = "k_wavefront" if os.environ.get("PP_WF_TILES") == "0" else "k_wavefront_tiles"
     # one roofline entry per kernel, each with ITS OWN time; `roofline` is the one that is busy longest per step
     roofs = {
-        "k_wavefront": dict(kernel="k_wavefront", bound="hbm", achieved=wf_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=wf_gbs / HBM_PEAK_GBS, traffic=None,
+        "k_wavefront": dict(kernel=WF_KERNEL, bound="hbm", achieved=wf_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=wf_gbs / HBM_PEAK_GBS, traffic=None,
                             ms_per_launch=wf, algorithmic_bytes_per_launch=wf_bytes),
         "search": dict(kernel=search_kernel, bound="hbm", achieved=se_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=se_gbs / HBM_PEAK_GBS, traffic=None,
                        ms_per_launch=se, algorithmic_bytes_per_launch=se_bytes),

@@ -104,12 +104,13 @@ def test_sampling_and_smoothing_default_interpolation():
     assert s["compared"] >= 12
 
 
-@pytest.mark.parametrize("iterations", [1, 3, 20, 100])
+@pytest.mark.parametrize("iterations", [1, 3, 10, 20])
 def test_default_spacing_descent_is_pinned_before_it_turns_chaotic(iterations):
-    """The hard assertion at the reference's default 0.1 m spacing: with Smoother::Parameters::maxIterations cut to 1 / 3 / 20 / 100 the
-    device's points after the last iteration equal the oracle's within 1e-5 on EVERY query, status included -- no escape clause.  (The two
-    descents stay within 1e-10 of each other for ~200 iterations, profiles/r03_smoother_divergence_query23.txt; beyond that the reference's
-    own result depends on the last bit of a cosine, which is what test_sampling_and_smoothing_default_interpolation documents.)  A defect in
+    """The hard assertion at the reference's default 0.1 m spacing: with Smoother::Parameters::maxIterations cut to 1 / 3 / 10 / 20 the
+    device's points after the last iteration equal the oracle's within 1e-5 on EVERY query, status included -- no escape clause.  (How long
+    the two descents stay together depends on the query: ~200 iterations within 1e-10 on query 23, profiles/r03_smoother_divergence_query23.txt,
+    but 1.6 cm apart after 100 on query 2 of this set; beyond that the reference's own result depends on the last bit of a cosine, which is
+    what test_sampling_and_smoothing_default_interpolation documents.)  A defect in
     the device smoother at this spacing -- gradient terms, their order, the float / double mix of smoother.cpp:160-214 -- fails here."""
     w, ms, val, ctx = make_pair(256, 6, 3)
     s = run(w, ms, val, 24, 5, 0.1, smoother=dict(max_iterations=iterations), strict_points=True)
