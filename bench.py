@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--pipe-rows", type=int, default=4096, help="--mode pipeline: rows of the persistent search grid")
     ap.add_argument("--map-source", choices=("product", "synthetic"), default="product",
                     help="product: outlines -> pp_map_set_cells -> pp_map_update_gvd_ex(REFERENCE_ORDER) (the library's own map pipeline); synthetic: numpy / scipy generator of rounds 1-2")
+    ap.add_argument("--sample-alive", action="store_true", help="diagnostics: sample the number of live search waves four times a second (a blocking copy each)")
     ap.add_argument("--submit-chunk", type=int, default=4096, help="--mode pipeline: queries per submission (= per wavefront launch)")
     args = ap.parse_args()
 
@@ -116,7 +117,7 @@ def main():
     if pipeline_mode:
         c = pa.Context(local_rank)
         ms_i, val_i = synthetic.upload(c, m)
-        cap = args.capacity if args.capacity > 0 else 6 * B
+        cap = args.capacity if args.capacity > 0 else max(6 * B, 3 * args.submit_chunk)  # (a submission must fit: steps smaller than a submission share one)
         pipe = pa.HybridAStarPipeline(val_i, params, capacity=cap, max_nodes=args.max_nodes, search_rows=args.pipe_rows)
         pipe.initialize()  # non-holonomic table built on the device
 
@@ -220,6 +221,7 @@ def main():
     last_paths = np.zeros((B, PATH_POSES, 3))  # the last step's plans, by query index
     last_path_n = np.zeros(B, dtype=np.int32)
     path_stats = {}
+    alive_samples = []
 
     def run_steps_pipeline(k):
         """k steps = k x B queries through the library's pipeline: submitted as slots are free, polled in completion order.  Returns the
@@ -235,7 +237,12 @@ def main():
         path_stats.update(paths=0, poses=0, longest=0, truncated=0, with_solution=0)
         t_run0 = time.perf_counter()
         last_submit = [0.0]
+        alive_samples.clear()
+        t_alive = time.perf_counter()
         while done < total:
+            if args.sample_alive and time.perf_counter() - t_alive > 0.25:  # diagnostics: is the search grid still whole?
+                t_alive = time.perf_counter()
+                alive_samples.append((round(t_alive - t_run0, 2), pipe.alive_waves()))
             if submitted < total:
                 free = pipe.free_slots()
                 off = submitted % (rep * B)
@@ -572,6 +579,7 @@ def main():
                                           run_sums["rng_draws"] == args.steps * sum(r.n_rng_draws for r in res) and run_sums["state_checks"] == args.steps * state_checks),
                 "paths_fetched": path_stats.get("paths"), "paths_with_solution": path_stats.get("with_solution"), "path_poses_fetched": path_stats.get("poses"), "longest_path_nodes": path_stats.get("longest"),
                 "paths_longer_than_fetched": path_stats.get("truncated"),
+                **({"alive_search_waves": alive_samples} if args.sample_alive else {}),
                 "run_profile": dict(tail_info), "pipeline_backlog": dict(samples=len(backlog), ready_mean=float(np.mean([b[0] for b in backlog])), ready_p10=float(np.percentile([b[0] for b in backlog], 10)),
                                          ready_max=int(max(b[0] for b in backlog)), searching_mean=float(np.mean([b[1] for b in backlog])), rows=pipe.search_rows)} if pipeline_mode else {}),
             "cpu_baseline": cpu,

@@ -379,6 +379,8 @@ int pp_pipeline_release(pp_pipeline* pipeline, int32_t n, const uint64_t* ticket
  * path's remaining records are fetched from the device).  release != 0: the slots are returned like pp_pipeline_release. */
 int pp_pipeline_get_paths(pp_pipeline* pipeline, int32_t n, const uint64_t* tickets, int32_t max_poses, double* poses_host, int32_t* n_poses_host, int32_t release);
 int pp_pipeline_slot_of(pp_pipeline* pipeline, uint64_t ticket); /* -1 unless completed and held */
+/* Diagnostics: waves of the search grid that are alive right now (a blocking device-to-host copy; -1 on error). */
+int pp_pipeline_alive_waves(pp_pipeline* pipeline);
 pp_planner* pp_pipeline_planner(pp_pipeline* pipeline);           /* the buffer set: set_nonholo_table, set_primitives, get_path(slot), ... */
 int pp_pipeline_capacity(pp_pipeline* pipeline);
 int pp_pipeline_search_rows(pp_pipeline* pipeline);

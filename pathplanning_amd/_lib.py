@@ -178,7 +178,7 @@ def load():
     L.pp_pipeline_backlog.argtypes = [vp, vp, vp]
     L.pp_pipeline_planner.argtypes = [vp]
     L.pp_pipeline_planner.restype = vp
-    for f in ("pp_pipeline_capacity", "pp_pipeline_search_rows", "pp_pipeline_in_flight", "pp_pipeline_free_slots"):
+    for f in ("pp_pipeline_capacity", "pp_pipeline_search_rows", "pp_pipeline_in_flight", "pp_pipeline_free_slots", "pp_pipeline_alive_waves"):
         getattr(L, f).argtypes = [vp]
     L.pp_planner_postprocess.argtypes = [vp, C.c_int32, C.c_float, vp, C.c_int32, vp]
     L.pp_planner_get_processed_path.argtypes = [vp, C.c_int32, vp, vp, vp]

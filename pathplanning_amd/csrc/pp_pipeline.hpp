@@ -168,7 +168,8 @@ struct pp_pipeline {
 	int32_t* errFlags = nullptr; // [streams] the wavefront kernels' error flags, in pinned host memory: written by the device, read by poll
 	double* pathHost = nullptr;  // [capacity][pathHostCap][3]: the poses of every finished query's solution path, goal first, written by the row that finished it
 	int pathHostCap = 192;       // poses per slot in that ring (longer paths: the rest is fetched from the device records); PP_PIPE_PATH_POSES
-	unsigned long long lingerTicks = 0; // PP_PIPE_LINGER_MS: how long an idle search wave stays after everything submitted has been claimed (0: it leaves at once)
+	unsigned long long lingerTicks = 0; // PP_PIPE_LINGER_MS: how long an idle search wave stays after everything submitted has been claimed (default: the idle time-out)
+	unsigned long long quiesced = 0;    // the submission count last written to PipeCtl::quiesce
 	bool dead = false;           // a submission failed half way: the pipeline's accounting is no longer trustworthy (every later call fails)
 	unsigned long long lastTail = 0, lastHead = 0; // the ready queue's counters as the latest completion record saw them
 	// streams
@@ -328,8 +329,20 @@ int pipe_launch_search(pp_pipeline* P)
 	*src = P->nSubmitted;
 	PP_HIP_TRY(hipMemcpyAsync(&P->ctl->nSubmitted, src, 8, hipMemcpyHostToDevice, P->ctlStream));
 	PP_HIP_TRY(hipEventRecord(P->evCtl, P->ctlStream));
-	hipStream_t s = P->searchStream[P->nextSearch];
-	P->nextSearch = (P->nextSearch + 1) % kPipeSearchStreams;
+	// a launch starts only when the previous launch on its stream has ended, i.e. when every wave of that launch has left: the top-up goes to
+	// a stream that is idle; if every stream still carries live waves there is nothing to top up through (the waves alive keep taking work)
+	hipStream_t s = nullptr;
+	for (int i = 0; i < kPipeSearchStreams && !s; i++) {
+		const int k = (P->nextSearch + i) % kPipeSearchStreams;
+		if (hipStreamQuery(P->searchStream[k]) == hipSuccess) {
+			s = P->searchStream[k];
+			P->nextSearch = (k + 1) % kPipeSearchStreams;
+		}
+	}
+	if (!s) {
+		P->lastLaunch = std::chrono::steady_clock::now();
+		return PP_OK;
+	}
 	PP_HIP_TRY(hipStreamWaitEvent(s, P->evCtl, 0));
 	constexpr int kWg = 1; // (single-wave workgroups: see k_hybrid_search_rows)
 	pl->args.rowsWaves = P->waves;
@@ -572,14 +585,15 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 			if (x >= 1 && x < P->wfBlocks)
 				P->wfBlocks = (int)x;
 		}
-		if (const char* lg = getenv("PP_PIPE_LINGER_MS")) {
-			const double ms = strtod(lg, nullptr);
-			P->lingerTicks = (unsigned long long)((ms < 0 ? 0 : (ms > 1000 ? 1000 : ms)) * 250.0);
-		}
 		const char* v = getenv("PP_PIPE_IDLE_MS"); // how long a wave waits for work that does not come before it leaves on its own
 		if (v && *v) {
 			const long ms = strtol(v, nullptr, 10);
 			P->idleTicks = (unsigned long long)(ms < 1 ? 1 : (ms > 10000 ? 10000 : ms)) * 250ull;
+		}
+		P->lingerTicks = P->idleTicks; // idle waves stay until the idle time-out or until the host has polled everything (see k_hybrid_search_rows)
+		if (const char* lg = getenv("PP_PIPE_LINGER_MS")) {
+			const double ms = strtod(lg, nullptr);
+			P->lingerTicks = (unsigned long long)((ms < 0 ? 0 : (ms > 1000 ? 1000 : ms)) * 250.0);
 		}
 	}
 	*out = P;
@@ -819,6 +833,17 @@ int pp_pipeline_poll(pp_pipeline* P, int32_t max_results, uint64_t* tickets_out,
 		set_error("obstacle-heuristic open list exceeded its workspace: the pipeline must be destroyed (the results returned with this call are valid)");
 		return PP_ERR_CAPACITY;
 	}
+	if (P->nSubmitted == P->doneHead && P->quiesced != P->nSubmitted) {
+		// every result has been polled: the idle waves of the search grid may leave at once instead of waiting out their time-out (a device
+		// synchronisation then returns promptly).  One 8-byte copy per such transition -- not per poll.
+		PP_HIP_TRY(hipSetDevice(pl->map->ctx->device));
+		if ((P->submittedStagePos & 31) == 31)
+			PP_HIP_TRY(hipStreamSynchronize(P->ctlStream));
+		unsigned long long* const src = P->submittedStage + (P->submittedStagePos++ & 63);
+		*src = P->nSubmitted;
+		PP_HIP_TRY(hipMemcpyAsync(&P->ctl->quiesce, src, 8, hipMemcpyHostToDevice, P->ctlStream));
+		P->quiesced = P->nSubmitted;
+	}
 	if (P->nSubmitted > P->doneHead) {
 		// waves that left on their own (no work for idleTicks) are replaced while queries are outstanding
 		const auto now = std::chrono::steady_clock::now();
@@ -952,6 +977,20 @@ int pp_pipeline_backlog(pp_pipeline* P, int64_t* ready, int64_t* searching)
 	if (searching)
 		*searching = (int64_t)(P->lastHead - P->doneHead);
 	return PP_OK;
+}
+
+/// Diagnostics: how many waves of the search grid own their index right now (a blocking copy of the ownership words: not for the hot path).
+int pp_pipeline_alive_waves(pp_pipeline* P)
+{
+	if (!P)
+		return -1;
+	std::vector<int> a((size_t)P->waves);
+	if (hipSetDevice(P->pl->map->ctx->device) != hipSuccess || hipMemcpy(a.data(), P->waveAlive, (size_t)P->waves * 4, hipMemcpyDeviceToHost) != hipSuccess)
+		return -1;
+	int n = 0;
+	for (int v : a)
+		n += v != 0;
+	return n;
 }
 
 /// field slot of a completed query that is still held (polled with release = 0): the index the pp_planner_get_* accessors of

@@ -1156,7 +1156,8 @@ struct PipeCtl {
 	unsigned long long doneTail;   // completion records reserved
 	unsigned long long nSubmitted; // queries handed to the wavefront kernel so far (written by the host, in stream order before a top-up launch)
 	int stop;                      // host: leave as soon as the rows are idle
-	int pad[3];
+	int pad;
+	unsigned long long quiesce;    // host: every result of the first `quiesce` submitted queries has been polled -- idle waves need not wait for more
 	unsigned long long urgentTail; // urgent ring (WavefrontPublish::urgent): entries appended by k_pipe_scatter
 	unsigned long long urgentHead; // entries claimed by wavefront workgroups
 };

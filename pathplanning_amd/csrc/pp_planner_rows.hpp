@@ -592,7 +592,13 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				const unsigned long long head = __hip_atomic_load(&pipe.ctl->readyHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				const int stop = __hip_atomic_load(&pipe.ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				const bool timedOut = (unsigned long long)idleIters > pipe.idleTicks;
-				if (stop || (head >= sub && (unsigned long long)idleIters >= pipe.lingerTicks) || timedOut) {
+				// (a wave that left because everything submitted had been claimed used to come back with the next submission's top-up launch -- but a
+				// top-up launch runs only when the previous launch on its stream has ENDED, and with a few waves of every earlier launch still alive
+				// no stream's launch ever ends: measured, 64-step run, 1024 waves alive for 3.8 s, then 245 for the remaining 12 s with 12 000 fields
+				// waiting.  So idle waves now stay -- for `lingerTicks`, by default the idle time-out -- until the host says that every result has been
+				// polled (`quiesce`), and the top-up launches only replace waves that timed out.)
+				const unsigned long long qui = __hip_atomic_load(&pipe.ctl->quiesce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (stop || (head >= sub && ((unsigned long long)idleIters >= pipe.lingerTicks || qui >= sub)) || timedOut) {
 					// the wave index goes back first, THEN the submission count is read again: a top-up launch that found this index
 					// still owned was started after its submission count was written, so one of the two sees the other
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

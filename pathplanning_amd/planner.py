@@ -753,6 +753,10 @@ class HybridAStarPipeline:
     def in_flight(self):
         return self.lib.pp_pipeline_in_flight(self.h)
 
+    def alive_waves(self):
+        """diagnostics: waves of the search grid that own their index right now (blocking copy)"""
+        return self.lib.pp_pipeline_alive_waves(self.h)
+
     def free_slots(self):
         return self.lib.pp_pipeline_free_slots(self.h)
 
