@@ -246,7 +246,7 @@ def main():
             if submitted < total:
                 free = pipe.free_slots()
                 off = submitted % (rep * B)
-                want = min(rep * B - off, args.submit_chunk, total - submitted)
+                want = min(rep * B - off, args.submit_chunk, total - submitted, pipe.capacity)  # (never more than the pipeline can hold: the loop would wait for ever)
                 if free >= want:  # a submission is one wavefront launch: never a handful of goals (a launch lasts at least one goal's 20 ms)
                     first, kk = pipe.submit_dev(d_starts_rep, d_goals_rep, d_seeds_rep, n=want, offset=off)
                     if base is None:

@@ -193,7 +193,9 @@ struct pp_pipeline {
 	std::vector<Timed> timedFree, timedBusy;
 	double wfMs = 0, searchMs = 0, searchMaxMs = 0;
 	long long wfLaunches = 0, wfGoals = 0, searchLaunches = 0;
-	unsigned long long idleTicks = 12500ull; // idle loop passes of ~4 us: about 50 ms
+	unsigned long long idleTicks = 250000ull; // idle loop passes of ~4 us: about 1 s.  (50 ms until round 4: shorter than the ~100 ms the first fields of a run take, so the
+	                                         // grid's waves left before their first work arrived and came back by the luck of the top-up launches.)  Idle waves leave at once when
+	                                         // the host has polled every result (PipeCtl::quiesce), so the time-out only matters when a producer really cannot run.
 	int nWf = 2;      // wavefront streams in use: consecutive submissions' launches overlap (the tail of one under the head of the next)
 	int wfBlocks = 0; // workgroups per wavefront launch (<= the resident number): the wavefront kernel's share of the chip
 };

@@ -180,8 +180,11 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 	const int TR = (rows + TT - 1) / TT, TC = (cols + TW - 1) / TW, nTiles = TR * TC;
 	float* const L = reinterpret_cast<float*>(smemRaw);                // [LN] the tile being solved, halo included
 	const uint32_t* const Lu = smemRaw;
-	float* const prio = L + LNP;                                       // [nTiles] smallest changed halo cost of a queued tile, +inf = not queued
-	uint8_t* const tstate = reinterpret_cast<uint8_t*>(prio + nTiles); // [nTiles] bit 0: solved at least once
+	// the goal's tile queue: 16 bits per tile -- bits 0..14 the bucket of the smallest changed halo cost of a QUEUED tile (0x7FFF = not queued),
+	// bit 15 "solved at least once".  (Four bytes + one per tile until the 4096^2 map of config 5 needed 41 KB of LDS per wave for it: two waves per CU.)
+	uint16_t* const tq = reinterpret_cast<uint16_t*>(L + LNP); // [nTiles, padded to an even number]
+	const uint32_t* const tq32 = reinterpret_cast<const uint32_t*>(tq);
+	constexpr uint32_t kNotQueued = 0x7FFFu;
 	const float kInf = __builtin_huge_valf();
 	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
 	const int64_t cells = (int64_t)rows * cols;
@@ -263,13 +266,11 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 		float* const cost = A.costOut + (int64_t)g * fieldElems;
 		const int goalR = start >= 0 ? start / cols : -1, goalC = start >= 0 ? start - goalR * cols : -1;
 
-		for (int t = lane; t < nTiles; t += 64) {
-			prio[t] = kInf;
-			tstate[t] = 0;
-		}
+		for (int t = lane; t < ((nTiles + 1) & ~1); t += 64)
+			tq[t] = (uint16_t)kNotQueued;
 		wave_sync();
 		if (start >= 0 && lane == 0)
-			prio[(goalR / TT) * TC + goalC / TW] = 0.0f;
+			tq[(goalR / TT) * TC + goalC / TW] = 0;
 		wave_sync();
 		bool flagged = false; // a tie of (*) somewhere, or the visit budget spent
 		int visits = 0;
@@ -277,17 +278,22 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 
 		for (;;) {
 			// ---- the queued tile whose changed halo is cheapest
-			uint32_t bestBits = kInfBits;
+			uint32_t bestBits = kNotQueued;
 			int bestT = -1;
-			for (int t = lane; t < nTiles; t += 64) {
-				const uint32_t pb = __float_as_uint(prio[t]);
-				if (pb < bestBits) {
-					bestBits = pb;
-					bestT = t;
+			for (int t2 = lane; t2 < (nTiles + 1) / 2; t2 += 64) { // two tiles per word
+				const uint32_t w = tq32[t2];
+				const uint32_t lo = w & 0x7FFFu, hi = (w >> 16) & 0x7FFFu;
+				if (lo < bestBits) {
+					bestBits = lo;
+					bestT = 2 * t2;
+				}
+				if (hi < bestBits) {
+					bestBits = hi;
+					bestT = 2 * t2 + 1;
 				}
 			}
 			const uint32_t minBits = wave_min_u32(bestBits);
-			if (minBits == kInfBits)
+			if (minBits == kNotQueued)
 				break; // nothing queued: the field is settled
 			const uint64_t who = __ballot(bestBits == minBits);
 			const int t = __builtin_amdgcn_readlane(bestT, (int)__builtin_ctzll(who));
@@ -301,7 +307,7 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 			const int r0 = tr * TT, c0 = tc * TW;
 			auto solved = [&](int dtr, int dtc) -> bool {
 				const int a = tr + dtr, b = tc + dtc;
-				return a >= 0 && b >= 0 && a < TR && b < TC && (tstate[a * TC + b] & 1);
+				return a >= 0 && b >= 0 && a < TR && b < TC && (tq[a * TC + b] & 0x8000u);
 			};
 			const bool selfSolved = solved(0, 0);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the halo is read back from lines the previous visits stored
@@ -540,11 +546,13 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 				if (lane == 0) {
 					auto queue = [&](int dtr, int dtc, float p) {
 						const int a = tr + dtr, b = tc + dtc;
-						if (p < kInf && a >= 0 && b >= 0 && a < TR && b < TC && p < prio[a * TC + b])
-							prio[a * TC + b] = p;
+						if (p < kInf && a >= 0 && b >= 0 && a < TR && b < TC) {
+							const uint32_t bucket = p < 32766.0f ? (uint32_t)p : 32766u, old = tq[a * TC + b];
+							if (bucket < (old & 0x7FFFu))
+								tq[a * TC + b] = (uint16_t)((old & 0x8000u) | bucket);
+						}
 					};
-					prio[t] = kInf;
-					tstate[t] = 1;
+					tq[t] = (uint16_t)(0x8000u | kNotQueued); // solved, not queued
 					queue(-1, 0, qN);
 					queue(1, 0, qS);
 					queue(0, -1, qW);
@@ -571,7 +579,7 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 		// ---- +inf for the tiles the wavefront never reached (heuristics.cpp:108-113)
 		if (!flagged) {
 			for (int t = 0; t < nTiles; t++) {
-				if (tstate[t] & 1)
+				if (tq[t] & 0x8000u)
 					continue;
 				const int tr = t / TC, tc = t - tr * TC;
 				for (int u = 0; u < TW; u++) {
@@ -677,7 +685,7 @@ size_t tiles_lds_bytes(int rows, int cols)
 {
 	const int tw = tile_width();
 	const size_t nTiles = (size_t)((rows + TT - 1) / TT) * (size_t)((cols + tw - 1) / tw);
-	return ((size_t)(tw == 64 ? TileShape<64>::LNP : TileShape<32>::LNP) * 4 + nTiles * 4 + nTiles + 15) & ~(size_t)15;
+	return ((size_t)(tw == 64 ? TileShape<64>::LNP : TileShape<32>::LNP) * 4 + ((nTiles + 1) & ~(size_t)1) * 2 + 15) & ~(size_t)15;
 }
 
 /// waves per workgroup: as many as make the workgroup's LDS exceed half of a CU's 160 KB (see k_wavefront_tiles), at most 8
@@ -700,6 +708,8 @@ void launch_tiles_kernel(hipStream_t s, int waves, TilesArgs A)
 	const size_t lds = tiles_lds_bytes(A.m.rows, A.m.cols);
 	// packs protect the pipeline's persistent search grid; a launch outside a pipeline has the chip to itself: single waves, eight per CU
 	const int pack = A.pub.ready ? waves_per_pack(lds) : 1;
+	// (a pack of eight waves whose slices add up to less than half a CU's LDS asks for 82 KB all the same: one pack per CU is the point)
+	const size_t packLds = pack > 1 && (size_t)pack * lds < 82 * 1024 ? 82 * 1024 : (size_t)pack * lds;
 	A.ldsPerWave = (int)lds;
 	static const int prio = [] {
 		const char* e = getenv("PP_WF_TILES_PRIO");
@@ -718,14 +728,14 @@ void launch_tiles_kernel(hipStream_t s, int waves, TilesArgs A)
 	(void)attr;
 	if (tile_width() == 64) {
 		if (A.stats)
-			hipLaunchKernelGGL((k_wavefront_tiles<64, true>), dim3(grid), dim3(64 * pack), lds * pack, s, A);
+			hipLaunchKernelGGL((k_wavefront_tiles<64, true>), dim3(grid), dim3(64 * pack), packLds, s, A);
 		else
-			hipLaunchKernelGGL((k_wavefront_tiles<64, false>), dim3(grid), dim3(64 * pack), lds * pack, s, A);
+			hipLaunchKernelGGL((k_wavefront_tiles<64, false>), dim3(grid), dim3(64 * pack), packLds, s, A);
 	} else {
 		if (A.stats)
-			hipLaunchKernelGGL((k_wavefront_tiles<32, true>), dim3(grid), dim3(64 * pack), lds * pack, s, A);
+			hipLaunchKernelGGL((k_wavefront_tiles<32, true>), dim3(grid), dim3(64 * pack), packLds, s, A);
 		else
-			hipLaunchKernelGGL((k_wavefront_tiles<32, false>), dim3(grid), dim3(64 * pack), lds * pack, s, A);
+			hipLaunchKernelGGL((k_wavefront_tiles<32, false>), dim3(grid), dim3(64 * pack), packLds, s, A);
 	}
 }
 
@@ -748,7 +758,19 @@ hipError_t launch_occ_bits(hipStream_t s, const uint8_t* occ8, int rows, int col
 	return hipGetLastError();
 }
 
-bool wavefront_tiles_supported(int rows, int cols) { return tiles_lds_bytes(rows, cols) <= 64 * 1024; } // (dynamic LDS of a launch: packs of waves, <= 160 KB)
+bool wavefront_tiles_supported(int rows, int cols)
+{
+	// One wave per goal is a throughput form: at 4096^2 a goal keeps its wave for ~1 s next to the search grid, and the 1536 field slots of 64 MB that fit
+	// in HBM are too few goals in flight to hide that (config 5, measured: 466 plans/s against 677 with the ordered kernel's eight waves per goal).  Until a
+	// goal can spread over several waves the tile form takes maps up to 2048 x 2048 cells; PP_WF_TILES=2 lifts the limit.
+	static const bool anySize = [] {
+		const char* e = getenv("PP_WF_TILES");
+		return e && e[0] == '2';
+	}();
+	if (!anySize && (int64_t)rows * cols > (int64_t)2048 * 2048)
+		return false;
+	return tiles_lds_bytes(rows, cols) <= 64 * 1024; // (dynamic LDS of a launch: packs of waves, <= 160 KB)
+}
 
 int wavefront_tiles_resident_blocks(int rows, int cols)
 {
