@@ -118,6 +118,10 @@ def main():
         c = pa.Context(local_rank)
         ms_i, val_i = synthetic.upload(c, m)
         cap = args.capacity if args.capacity > 0 else max(6 * B, 3 * args.submit_chunk)  # (a submission must fit: steps smaller than a submission share one)
+        if args.submit_chunk > cap // 3:
+            # a submission waits for as many free slots as it has queries: one of a third of the capacity at most, or the pipeline runs empty
+            # before every submission (config 5 with --capacity 1536 and the default chunk of 4096: 470 plans/s instead of 680)
+            args.submit_chunk = max(B, cap // 3 // B * B)
         pipe = pa.HybridAStarPipeline(val_i, params, capacity=cap, max_nodes=args.max_nodes, search_rows=args.pipe_rows)
         pipe.initialize()  # non-holonomic table built on the device
 

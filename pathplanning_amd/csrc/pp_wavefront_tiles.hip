@@ -709,7 +709,12 @@ void launch_tiles_kernel(hipStream_t s, int waves, TilesArgs A)
 	// packs protect the pipeline's persistent search grid; a launch outside a pipeline has the chip to itself: single waves, eight per CU
 	const int pack = A.pub.ready ? waves_per_pack(lds) : 1;
 	// (a pack of eight waves whose slices add up to less than half a CU's LDS asks for 82 KB all the same: one pack per CU is the point)
-	const size_t packLds = pack > 1 && (size_t)pack * lds < 82 * 1024 ? 82 * 1024 : (size_t)pack * lds;
+	static const size_t minPackLds = [] {
+		const char* e = getenv("PP_WF_TILES_PACK_KB"); // tuning: LDS a pack asks for at least (a search grid with more waves per CU leaves less than 82 KB)
+		const int v = e ? atoi(e) : 82;
+		return (size_t)(v < 1 ? 1 : (v > 160 ? 160 : v)) * 1024;
+	}();
+	const size_t packLds = pack > 1 && (size_t)pack * lds < minPackLds ? minPackLds : (size_t)pack * lds;
 	A.ldsPerWave = (int)lds;
 	static const int prio = [] {
 		const char* e = getenv("PP_WF_TILES_PRIO");
