@@ -193,6 +193,7 @@ struct pp_pipeline {
 	std::vector<Timed> timedFree, timedBusy;
 	double wfMs = 0, searchMs = 0, searchMaxMs = 0;
 	long long wfLaunches = 0, wfGoals = 0, searchLaunches = 0;
+	int soloAfter = 40000, soloBacklog = 256; // PP_PIPE_SOLO_AFTER / PP_PIPE_SOLO_BACKLOG: see k_hybrid_search_rows (0 = off)
 	unsigned long long idleTicks = 250000ull; // idle loop passes of ~4 us: about 1 s.  (50 ms until round 4: shorter than the ~100 ms the first fields of a run take, so the
 	                                         // grid's waves left before their first work arrived and came back by the luck of the top-up launches.)  Idle waves leave at once when
 	                                         // the host has polled every result (PipeCtl::quiesce), so the time-out only matters when a producer really cannot run.
@@ -312,6 +313,8 @@ PipeView pipe_view(const pp_pipeline* P)
 	v.waveAlive = P->waveAlive;
 	v.idleTicks = P->idleTicks;
 	v.lingerTicks = P->lingerTicks;
+	v.soloAfter = P->soloAfter;
+	v.soloBacklog = P->soloBacklog;
 	v.pathHost = P->pathHost;
 	v.pathHostCap = P->pathHostCap;
 	return v;
@@ -591,6 +594,14 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		if (v && *v) {
 			const long ms = strtol(v, nullptr, 10);
 			P->idleTicks = (unsigned long long)(ms < 1 ? 1 : (ms > 10000 ? 10000 : ms)) * 250ull;
+		}
+		if (const char* sa = getenv("PP_PIPE_SOLO_AFTER")) {
+			const long x = strtol(sa, nullptr, 10);
+			P->soloAfter = x < 0 ? 0 : (x > 0x7FFFFFFF ? 0x7FFFFFFF : (int)x);
+		}
+		if (const char* sb = getenv("PP_PIPE_SOLO_BACKLOG")) {
+			const long x = strtol(sb, nullptr, 10);
+			P->soloBacklog = x < 0 ? 0 : (x > 0x7FFFFFFF ? 0x7FFFFFFF : (int)x);
 		}
 		P->lingerTicks = P->idleTicks; // idle waves stay until the idle time-out or until the host has polled everything (see k_hybrid_search_rows)
 		if (const char* lg = getenv("PP_PIPE_LINGER_MS")) {

@@ -1179,6 +1179,8 @@ struct PipeView {
 	double* pathHost = nullptr;       // pinned host memory, [capacity][pathHostCap][3]: the solution path's poses, goal first (write_path)
 	int pathHostCap = 0;
 	unsigned long long idleTicks = 0; // loop passes (~4 us each: a sleep and three polls) a wave waits without work before it leaves on its own
+	int soloAfter = 0;                // > 0: a wave one of whose rows has passed this many expansions takes no new queries while the ready ring holds fewer than soloBacklog
+	int soloBacklog = 0;
 };
 
 #include "pp_planner_rows.hpp"

@@ -95,12 +95,14 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 	int idleIters = 0; // (wave-uniform) consecutive loop passes with every row idle
 	unsigned passCount = 0; // (wave-uniform, pipeline) loop passes: a row that found the ring empty looks again every kPollEvery-th pass only
 	bool pollNow = true;    // (pipeline) this row looks at the ring on the next pass whatever the pass count (it has just finished a query, or lost a race)
-	size_t slot = (size_t)waveIdx * kRowsPerWave + (size_t)(lane >> 4);
-	Node* nodes = nodesBase + slot * A.maxNodes;
-	HeapEntry* heap = heapBase + slot * A.maxNodes;
-	uint32_t* keymap = keymapBase + slot * A.ks.size();
-	unsigned long long* mt = mtBase + slot * Mt64::N;
-	HeapEntry* bands = bandBase + slot * (size_t)(kBands * kBandCap);
+	int slot = waveIdx * kRowsPerWave + (lane >> 4);
+	Node* nodes = nodesBase + (size_t)slot * A.maxNodes;
+	uint32_t* keymap = keymapBase + (size_t)slot * A.ks.size();
+	// heap, engine state and bands are addressed from the slot where they are used (refills, flushes, one draw per expansion): six registers
+	// that need not live across the expansion loop
+#define ROW_HEAP (heapBase + (size_t)slot * A.maxNodes)
+#define ROW_MT (mtBase + (size_t)slot * Mt64::N)
+#define ROW_BANDS (bandBase + (size_t)slot * (size_t)(kBands * kBandCap))
 	const int firstSpareSlot = A.searchRows; // spare slots follow the rows' own
 	bool noSuspend = false; // no spare slot was left for this query
 
@@ -163,8 +165,6 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 	int mtIdx = 0;
 	int nExpanded = 0, nRngDraws = 0, nRsAttempts = 0, nRsLog = 0;
 	long long laneStateChecks = 0, lanePathChecks = 0, rsStateChecks = 0, rsPathChecks = 0;
-	int status = -1, solutionNode = -1;
-	double solutionCost = __builtin_huge_val();
 
 	// Entries that leave the front buffer are staged in LDS (spillBuf) and flushed sixteen at a time: every lane routes
 	// one entry to the ring slot of its f-band (a slot's position comes from an LDS atomic on the packed counters), the
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				const uint32_t old = atomicAdd(&bandCnt[sl >> 2], 1u << sh);
 				const int pos = (int)((old >> sh) & 0xFFu);
 				if (pos < kBandCap) {
-					bands[sl * kBandCap + pos] = mine;
+					ROW_BANDS[sl * kBandCap + pos] = mine;
 					toHeap = false;
 				} else {
 					atomicSub(&bandCnt[sl >> 2], 1u << sh);
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			if (rl == 0) {
 				int hs = heapSize;
 				for (uint32_t mm = hm; mm; mm &= mm - 1)
-					heap_push(heap, hs, spillBuf[__ffs((int)mm) - 1]);
+					heap_push(ROW_HEAP, hs, spillBuf[__ffs((int)mm) - 1]);
 			}
 			for (; hm; hm &= hm - 1) {
 				const HeapEntry e = spillBuf[__ffs((int)hm) - 1];
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			e.nseq = ~0u;
 			e.node = 0;
 			if (rl < n)
-				e = bands[sl * kBandCap + rl];
+				e = ROW_BANDS[sl * kBandCap + rl];
 			row_sort_entries(e.ckey, e.nseq, e.node, rl);
 			front.ckey = e.ckey;
 			front.nseq = e.nseq;
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		// heap entries that come before the buffer's last entry (or, with an empty buffer, the heap's best) move in
 		while (heapSize > 0 && (frontCount == 0 || key_before(heapTop.ckey, heapTop.nseq, row_read64(front.ckey, lane, frontCount - 1), row_read(front.nseq, lane, frontCount - 1)))) {
 			wave_vmem_sync();
-			const HeapEntry he = heap_pop_row(heap, heapSize, rl, lane, heapTop);
+			const HeapEntry he = heap_pop_row(ROW_HEAP, heapSize, rl, lane, heapTop);
 			wave_vmem_sync();
 			nOutside--;
 			HeapEntry sp;
@@ -317,14 +317,12 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		}
 	};
 	auto set_slot = [&](size_t sl_) {
-		slot = sl_;
-		nodes = nodesBase + slot * A.maxNodes;
-		heap = heapBase + slot * A.maxNodes;
-		keymap = keymapBase + slot * A.ks.size();
-		mt = mtBase + slot * Mt64::N;
-		bands = bandBase + slot * (size_t)(kBands * kBandCap);
+		slot = (int)sl_;
+		nodes = nodesBase + (size_t)slot * A.maxNodes;
+		keymap = keymapBase + (size_t)slot * A.ks.size();
 	};
-	auto finish = [&]() { // writes the result record of the row's query and frees the row
+	// (status / solution are parameters, not row state: they exist at the call sites only -- four registers less to keep alive across the expansion loop)
+	auto finish = [&](const int status, const int solutionNode, const double solutionCost) { // writes the result record of the row's query and frees the row
 		const long long nStateChecks = row_sum_i64(laneStateChecks, lane) + rsStateChecks;
 		const long long pathChecksPacked = row_sum_i64(lanePathChecks, lane) + rsPathChecks;
 		const long long pathChecks = pathChecksPacked & kGuardMask;
@@ -389,6 +387,11 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 #define ROWS_STAMP(ph)
 #endif
 	for (;;) {
+		// (pipeline) A wave iterates in ~30 us with four busy rows and in ~13 us with one, and a run ends with its longest chains of dependent expansions
+		// (the lattice-exhausting queries: 65 k): once a row's query has passed `soloAfter` expansions the wave's other rows take nothing new while the
+		// ready ring is short -- rows are idle then anyway (the wavefront stage paces the pipeline), and these are the ones that should be.  With a
+		// backlog of soloBacklog fields or more every row claims as before.
+		const bool waveLong = piped && pipe.soloAfter > 0 && __ballot(act && nExpanded >= pipe.soloAfter) != 0ull;
 		// ================= rows without a query take the next one =================
 		if (!act && !done) {
 			bool none = false;
@@ -406,7 +409,10 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				if (rl == 0 && look) {
 					unsigned long long h = __hip_atomic_load(&pipe.ctl->readyHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					const unsigned long long e = __hip_atomic_load(pipe.ready + (h & pipe.readyMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if ((uint32_t)(e >> 32) == (uint32_t)(h + 1ull))
+					bool take = (uint32_t)(e >> 32) == (uint32_t)(h + 1ull);
+					if (take && waveLong) // leave it to a wave without a long query unless fields are piling up
+						take = __hip_atomic_load(&pipe.ctl->readyTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - h >= (unsigned long long)pipe.soloBacklog;
+					if (take)
 						got = __hip_atomic_compare_exchange_strong(&pipe.ctl->readyHead, &h, h + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 							? (int)(uint32_t)e : -2;
 				}
@@ -450,11 +456,11 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				heapTop.nseq = ~0u;
 				heapTop.node = 0;
 				if (heapSize > 0)
-					heapTop = heap[0];
+					heapTop = ROW_HEAP[0];
 				// the open list was moved out of the front buffer at suspension: band window and slot counts come back, the
 				// lowest possible bound keeps everything out of the empty buffer until the first refill
 				{
-					const uint4* src = reinterpret_cast<const uint4*>(bandMetaBase + slot * (size_t)kBands);
+					const uint4* src = reinterpret_cast<const uint4*>(bandMetaBase + (size_t)slot * (size_t)kBands);
 					wave_lds_sync();
 					for (int i = rl; i < kBands / 16; i += kRowLanes)
 						reinterpret_cast<uint4*>(bandCnt)[i] = src[i];
@@ -475,9 +481,6 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				laneStateChecks = rl == 0 ? rec.stateChecks : 0; // the totals so far ride in the row's first lane
 				lanePathChecks = rl == 0 ? rec.pathChecks : 0;
 				rsStateChecks = rsPathChecks = 0;
-				status = -1;
-				solutionNode = -1;
-				solutionCost = __builtin_huge_val();
 				act = true;
 			} else {
 				if (order)
@@ -526,11 +529,8 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				seq = 1;
 				nExpanded = nRngDraws = nRsAttempts = nRsLog = 0;
 				laneStateChecks = lanePathChecks = rsStateChecks = rsPathChecks = 0;
-				status = -1;
-				solutionNode = -1;
-				solutionCost = __builtin_huge_val();
 				if (rl == 0)
-					Mt64::seed(mt, seeds[q]);
+					Mt64::seed(ROW_MT, seeds[q]);
 				mtIdx = Mt64::N; // engine freshly seeded: first draw twists
 				double rs_, rc_;
 				sincos(start.t, &rs_, &rc_);
@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 
 		// ================= one step of SearchPath's main loop (a_star.h:337-345) for every active row =================
 		if (!(frontCount > 0 || nOutside > 0)) {
-			finish(); // open list exhausted: status stays -1
+			finish(-1, -1, __builtin_huge_val()); // open list exhausted: status -1
 			continue;
 		}
 		// ---- setting a query aside: its open list goes entirely into the heap, the scalars into a SuspendRec of the next
@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 				if (nSpill > 0)
 					flush_spills();
 				{
-					uint4* dst = reinterpret_cast<uint4*>(bandMetaBase + slot * (size_t)kBands);
+					uint4* dst = reinterpret_cast<uint4*>(bandMetaBase + (size_t)slot * (size_t)kBands);
 					for (int i = rl; i < kBands / 16; i += kRowLanes)
 						dst[i] = reinterpret_cast<const uint4*>(bandCnt)[i];
 				}
@@ -769,10 +769,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 			continue; // entry of a node replaced by ProcessPossibleShortcut
 		const Pose ppose = { px, py, pt };
 		if (identical_poses(ppose, goal)) { // IsSolution, hybrid_a_star.h:193-196
-			status = 0;
-			solutionNode = ni;
-			solutionCost = pPathCost;
-			finish();
+			finish(0, ni, pPathCost);
 			continue;
 		}
 		// ---- Expand, a_star.h:377-409
@@ -791,7 +788,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		unsigned long long mtRaw = 0ull;
 		const bool gateDraws = !(hCost < 10.0);
 		if (gateDraws && mtIdx < Mt64::N)
-			mtRaw = mt[mtIdx];
+			mtRaw = ROW_MT[mtIdx];
 
 		bool capacity = false;
 		ROWS_STAMP(3) // node record, solution test, bookkeeping
@@ -1028,8 +1025,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		}
 		ROWS_STAMP(9) // node records
 		if (capacity) {
-			status = -4;
-			finish();
+			finish(-4, -1, __builtin_huge_val());
 			continue;
 		}
 
@@ -1039,9 +1035,9 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		if (gateDraws) {
 			if (mtIdx >= Mt64::N) {
 				wave_vmem_sync();
-				mt_twist_row(mt, rl);
+				mt_twist_row(ROW_MT, rl);
 				mtIdx = 0;
-				mtRaw = mt[0];
+				mtRaw = ROW_MT[0];
 			}
 			const double u = Mt64::uniform01(Mt64::temper(mtRaw));
 			mtIdx++;
@@ -1178,8 +1174,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 					}
 					if (push) {
 						if (nNodes >= maxNodes) {
-							status = -4;
-							finish();
+							finish(-4, -1, __builtin_huge_val());
 							continue;
 						}
 						const int idx = nNodes++;
@@ -1235,4 +1230,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		atomicAdd(&g_rowsStats[8 + lane], s_phase[lane]);
 #endif
 #undef ROWS_STAMP
+#undef ROW_HEAP
+#undef ROW_MT
+#undef ROW_BANDS
 }

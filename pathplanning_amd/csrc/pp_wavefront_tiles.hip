@@ -765,15 +765,8 @@ hipError_t launch_occ_bits(hipStream_t s, const uint8_t* occ8, int rows, int col
 
 bool wavefront_tiles_supported(int rows, int cols)
 {
-	// One wave per goal is a throughput form: at 4096^2 a goal keeps its wave for ~1 s next to the search grid, and the 1536 field slots of 64 MB that fit
-	// in HBM are too few goals in flight to hide that (config 5, measured: 466 plans/s against 677 with the ordered kernel's eight waves per goal).  Until a
-	// goal can spread over several waves the tile form takes maps up to 2048 x 2048 cells; PP_WF_TILES=2 lifts the limit.
-	static const bool anySize = [] {
-		const char* e = getenv("PP_WF_TILES");
-		return e && e[0] == '2';
-	}();
-	if (!anySize && (int64_t)rows * cols > (int64_t)2048 * 2048)
-		return false;
+	// (4096^2, config 5: 765 plans/s with the tile form against 647 with the ordered kernel -- one wave per goal for ~1 s there, four waves per CU because
+	// of the 16 KB tile queue: profiles/r04_occupancy_and_config5.txt)
 	return tiles_lds_bytes(rows, cols) <= 64 * 1024; // (dynamic LDS of a launch: packs of waves, <= 160 KB)
 }
 

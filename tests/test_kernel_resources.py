@@ -13,8 +13,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 # kernel -> (max scratch bytes per lane, max VGPR spills)
 LIMITS = {
     "k_wavefront<false>": (176, 43),  # v10 (no up-front +inf fill; measured 174 -> 168 ms for 4096 goals with these figures)
-    "k_hybrid_search_rows<false>": (416, 85),  # the batch form: unchanged by the pipeline form next to it
-    "k_hybrid_search_rows<true>": (552, 114),  # the pipeline form (ring claims, completion records, idle handling)
+    "k_hybrid_search_rows<false>": (384, 77),  # the batch form: unchanged by the pipeline form next to it
+    "k_hybrid_search_rows<true>": (528, 113),  # the pipeline form (ring claims, completion records, idle handling); 310 of its 347 scratch loads sit in the
+    # Reeds-Shepp block (0.9 % of the expansions), 26 in the per-expansion phases: tools/isa_spill_map.py, profiles/r04_search_spill_map.txt
     "k_hybrid_search<false>": (112, 0),
     "k_check_states": (0, 0),
     "k_check_states_fused": (0, 0),
