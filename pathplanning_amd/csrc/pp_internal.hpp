@@ -106,6 +106,8 @@ struct WavefrontPublish {
 	// certify (a tie of its fixed-point equation, a run that does not settle) are rebuilt by the ordered kernel, launched behind it on the same stream.
 	const uint64_t* occBits = nullptr; // pp_map::occBits: the occupancy as padded bit rows (word (row + 1) * wpr + col / 64 + 1, bit col % 64; one word of padding on
 	                                   // every side, everything outside the map occupied; occ_bits_dims), rebuilt with occ8
+	uint32_t* tilesQueue = nullptr;   // optional: tilesQueueWaves regions of wavefront_tiles_queue_words() words, one per wave of a launch (the tile queue in global memory)
+	int tilesQueueWaves = 0;
 	int* tilesCtl = nullptr;          // >= 8 ints, zero at allocation (the kernels set them back): tile goal counter, exit counter, handed-over count, ordered goal counter, exit counter
 	int32_t* tilesFallback = nullptr; // [>= number of goals a launch may take] the handed-over goals
 	unsigned long long* tilesStats = nullptr; // optional, 16 words: goals, tile visits, rounds, candidate passes, cells, handed over, wave cycles, ...
@@ -125,6 +127,8 @@ void occ_bits_dims(int rows, int cols, int& wpr, int& nWordRows);
 hipError_t launch_occ_bits(hipStream_t s, const uint8_t* occ8, int rows, int cols, uint64_t* bits);
 bool wavefront_tiles_supported(int rows, int cols);
 int wavefront_tiles_resident_blocks(int rows, int cols);
+/// words of global memory per wave of a launch for the tile queue (0: the map is small enough for the queue to stay in LDS)
+size_t wavefront_tiles_queue_words(int rows, int cols);
 hipError_t warm_up_wavefront_tiles(hipStream_t s, const ppd::MapView& m, int* ctlDev);
 hipError_t launch_wavefront_tiles(hipStream_t s, const ppd::MapView& m, int nGoals, const int32_t* goalCellsDev, float* costDev, bool tiledOut, const double* goalPosesDev,
 	const double* orderStartsDev, float* orderKeysDev, const WavefrontPublish& pub);

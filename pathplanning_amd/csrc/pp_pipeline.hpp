@@ -148,6 +148,8 @@ struct pp_pipeline {
 	std::vector<hipEvent_t> segmentEvents; // spare events
 	long long segmentWaits = 0;            // times a submission had to wait for a launch before reusing its segment (diagnostic)
 	void* wfWorkspace[kPipeWavefrontStreams] = {};
+	uint32_t* tilesQueue[kPipeWavefrontStreams] = {}; // per wavefront stream: the tile queues of a launch's waves in global memory (large maps: pph::wavefront_tiles_queue_words)
+	int tilesQueueWaves = 0;
 	int32_t* wfCtl[kPipeWavefrontStreams] = {}; // per wavefront stream: {error flag, goal counter, exit counter, ...}
 	// The tile form's control words and hand-over lists, one SET per launch in flight: the ordered kernel's launch over a tile launch's
 	// handed-over goals runs on `fbStream`, behind the tile launch and beside the wavefront stream's next one, and reads its set until it ends
@@ -193,7 +195,7 @@ struct pp_pipeline {
 	std::vector<Timed> timedFree, timedBusy;
 	double wfMs = 0, searchMs = 0, searchMaxMs = 0;
 	long long wfLaunches = 0, wfGoals = 0, searchLaunches = 0;
-	int soloAfter = 40000, soloBacklog = 256; // PP_PIPE_SOLO_AFTER / PP_PIPE_SOLO_BACKLOG: see k_hybrid_search_rows (0 = off)
+	int soloAfter = 0, soloBacklog = 256; // PP_PIPE_SOLO_AFTER / PP_PIPE_SOLO_BACKLOG: see k_hybrid_search_rows (0 = off, the default: measured neutral, profiles/r04_solo_sweep.txt)
 	unsigned long long idleTicks = 250000ull; // idle loop passes of ~4 us: about 1 s.  (50 ms until round 4: shorter than the ~100 ms the first fields of a run take, so the
 	                                         // grid's waves left before their first work arrived and came back by the luck of the top-up launches.)  Idle waves leave at once when
 	                                         // the host has polled every result (PipeCtl::quiesce), so the time-out only matters when a producer really cannot run.
@@ -239,7 +241,7 @@ void free_pipeline(pp_pipeline* P)
 			if (t.b)
 				(void)hipEventDestroy(t.b);
 		}
-	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->urgent, P->claimed, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfWorkspace[2], P->wfWorkspace[3], P->wfCtl[0], P->wfCtl[1], P->wfCtl[2], P->wfCtl[3], P->fbCtl[0], P->fbCtl[1], P->fbCtl[2], P->fbCtl[3], P->fbCtl[4], P->fbCtl[5], P->fbCtl[6], P->fbCtl[7],
+	void* dev[] = { P->ctl, P->ready, P->waveAlive, P->urgent, P->claimed, P->slotLists, P->wfWorkspace[0], P->wfWorkspace[1], P->wfWorkspace[2], P->wfWorkspace[3], P->tilesQueue[0], P->tilesQueue[1], P->tilesQueue[2], P->tilesQueue[3], P->wfCtl[0], P->wfCtl[1], P->wfCtl[2], P->wfCtl[3], P->fbCtl[0], P->fbCtl[1], P->fbCtl[2], P->fbCtl[3], P->fbCtl[4], P->fbCtl[5], P->fbCtl[6], P->fbCtl[7],
 		P->fbList[0], P->fbList[1], P->fbList[2], P->fbList[3], P->fbList[4], P->fbList[5], P->fbList[6], P->fbList[7] };
 	for (void* q : dev)
 		if (q)
@@ -432,6 +434,11 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	};
 	for (int i = 0; i < P->nWf && e == hipSuccess; i++) {
 		e = hipMalloc(&P->wfWorkspace[i], (size_t)pl->wfBytesPerSlot * pl->wfSlots);
+		if (const size_t qw = pph::wavefront_tiles_queue_words(pl->map->desc.rows, pl->map->desc.cols)) {
+			P->tilesQueueWaves = 2048; // (256 CUs x 8 waves of a pack)
+			if (e == hipSuccess)
+				e = hipMalloc((void**)&P->tilesQueue[i], qw * 4 * (size_t)P->tilesQueueWaves);
+		}
 		if (e == hipSuccess)
 			e = hipMalloc((void**)&P->wfCtl[i], 64);
 		if (e == hipSuccess)
@@ -711,6 +718,7 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	}
 	// ---- inputs into their slots: on the control stream (never busy for long), so the caller's arrays are free when this returns
 	hipStream_t const w = P->wfStream[P->nextWf];
+	const int wfIdx = P->nextWf;
 	int32_t* const wctl = P->wfCtl[P->nextWf];
 	const int fbSet = P->nextFbSet;
 	P->nextFbSet = (P->nextFbSet + 1) % pp_pipeline::kFbSets;
@@ -743,6 +751,8 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 	pub.occBits = pl->map->occBits;
 	pub.tilesCtl = P->fbCtl[fbSet];
 	pub.tilesFallback = P->fbList[fbSet];
+	pub.tilesQueue = P->tilesQueue[wfIdx];
+	pub.tilesQueueWaves = P->tilesQueue[wfIdx] ? P->tilesQueueWaves : 0;
 	pub.fallbackStream = P->fbStream;
 	pub.fallbackEvent = P->fbAfterTiles[fbSet];
 	if (P->urgentClearance != 0.0f) {

@@ -29,6 +29,7 @@
 //     budget is handed to the ordered kernel like a tie.
 // Measured figures (tile visits per tile, rounds per visit, passes per round): DESIGN.md 4.3b.
 // Algorithmic bytes as for the ordered kernel: 9 B/cell.
+#include <cstdio>
 #include "pp_internal.hpp"
 
 #include <cstdlib>
@@ -150,7 +151,11 @@ struct TilesArgs {
 // goals).  Waves are packed so that the workgroup's LDS exceeds half a CU's: at most one pack per CU, which always leaves room for a
 // workgroup of the search grid (57 KB, 256 VGPRs per wave) next to it -- single-wave workgroups fill every CU's LDS eight at a time and
 // keep the persistent search grid's workgroups from becoming resident (measured: 4096 search rows, 1000 of them busy).
-template <int TW, bool kProf>
+// kGQ: the goal's tile queue lives in global memory (one region per wave of the launch, A.pub.tilesQueue) instead of LDS.  At 4096^2 the queue
+// is 16 KB per wave against 9 KB for the tile itself -- four waves per CU with it in LDS, eight without; the queue is read once per tile visit
+// (16 KB from the L2 against a visit's ~100 rounds) and written by lane 0 only, through agent-scope accesses (the wave's own L1 is not coherent
+// with its stores).
+template <int TW, bool kProf, bool kGQ>
 __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 {
 	// kProf (diagnostic instantiation, pp_obstacle_heuristic_tiles_stats): shader-clock sums per phase of a tile visit
@@ -182,9 +187,32 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 	const uint32_t* const Lu = smemRaw;
 	// the goal's tile queue: 16 bits per tile -- bits 0..14 the bucket of the smallest changed halo cost of a QUEUED tile (0x7FFF = not queued),
 	// bit 15 "solved at least once".  (Four bytes + one per tile until the 4096^2 map of config 5 needed 41 KB of LDS per wave for it: two waves per CU.)
-	uint16_t* const tq = reinterpret_cast<uint16_t*>(L + LNP); // [nTiles, padded to an even number]
-	const uint32_t* const tq32 = reinterpret_cast<const uint32_t*>(tq);
+	uint16_t* const tqL = reinterpret_cast<uint16_t*>(L + LNP); // [nTiles, padded to an even number]
+	const int nTileWords = (nTiles + 1) >> 1;
+	uint32_t* const tqG = kGQ ? A.pub.tilesQueue + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (size_t)nTileWords : nullptr;
 	constexpr uint32_t kNotQueued = 0x7FFFu;
+	auto tq_word = [&](int w) -> uint32_t { // two tiles
+		if (kGQ)
+			return __hip_atomic_load(tqG + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return reinterpret_cast<const uint32_t*>(tqL)[w];
+	};
+	auto tq_get = [&](int t) -> uint32_t {
+		if (kGQ)
+			return (uint32_t)__hip_atomic_load(reinterpret_cast<uint16_t*>(tqG) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return (uint32_t)tqL[t];
+	};
+	auto tq_set = [&](int t, uint32_t v) { // (lanes write different tiles)
+		if (kGQ)
+			__hip_atomic_store(reinterpret_cast<uint16_t*>(tqG) + t, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else
+			tqL[t] = (uint16_t)v;
+	};
+	auto tq_sync = [&]() { // lane 0's queue writes before the other lanes' reads
+		if (kGQ)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		else
+			wave_sync();
+	};
 	const float kInf = __builtin_huge_valf();
 	const float kDiag = sqrtf(2.0f); // std::sqrt(2.0f), heuristics.cpp:134
 	const int64_t cells = (int64_t)rows * cols;
@@ -266,12 +294,17 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 		float* const cost = A.costOut + (int64_t)g * fieldElems;
 		const int goalR = start >= 0 ? start / cols : -1, goalC = start >= 0 ? start - goalR * cols : -1;
 
-		for (int t = lane; t < ((nTiles + 1) & ~1); t += 64)
-			tq[t] = (uint16_t)kNotQueued;
-		wave_sync();
+		if (kGQ) {
+			for (int w = lane; w < nTileWords; w += 64)
+				__hip_atomic_store(tqG + w, kNotQueued | (kNotQueued << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			for (int t = lane; t < ((nTiles + 1) & ~1); t += 64)
+				tqL[t] = (uint16_t)kNotQueued;
+		}
+		tq_sync();
 		if (start >= 0 && lane == 0)
-			tq[(goalR / TT) * TC + goalC / TW] = 0;
-		wave_sync();
+			tq_set((goalR / TT) * TC + goalC / TW, 0u);
+		tq_sync();
 		bool flagged = false; // a tie of (*) somewhere, or the visit budget spent
 		int visits = 0;
 		const int visitBudget = 6 * nTiles + 64;
@@ -280,8 +313,10 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 			// ---- the queued tile whose changed halo is cheapest
 			uint32_t bestBits = kNotQueued;
 			int bestT = -1;
+			if (kGQ)
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the previous visit's queue entries (written by lanes 0..8, read by all)
 			for (int t2 = lane; t2 < (nTiles + 1) / 2; t2 += 64) { // two tiles per word
-				const uint32_t w = tq32[t2];
+				const uint32_t w = tq_word(t2);
 				const uint32_t lo = w & 0x7FFFu, hi = (w >> 16) & 0x7FFFu;
 				if (lo < bestBits) {
 					bestBits = lo;
@@ -307,7 +342,7 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 			const int r0 = tr * TT, c0 = tc * TW;
 			auto solved = [&](int dtr, int dtc) -> bool {
 				const int a = tr + dtr, b = tc + dtc;
-				return a >= 0 && b >= 0 && a < TR && b < TC && (tq[a * TC + b] & 0x8000u);
+				return a >= 0 && b >= 0 && a < TR && b < TC && (tq_get(a * TC + b) & 0x8000u);
 			};
 			const bool selfSolved = solved(0, 0);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the halo is read back from lines the previous visits stored
@@ -543,24 +578,19 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 				}
 				const float qN = wave_min_nonneg(pN), qS = wave_min_nonneg(pS), qW = wave_min_nonneg(pW), qE = wave_min_nonneg(pE);
 				const float qNW = wave_min_nonneg(pNW), qNE = wave_min_nonneg(pNE), qSW = wave_min_nonneg(pSW), qSE = wave_min_nonneg(pSE);
-				if (lane == 0) {
-					auto queue = [&](int dtr, int dtc, float p) {
-						const int a = tr + dtr, b = tc + dtc;
-						if (p < kInf && a >= 0 && b >= 0 && a < TR && b < TC) {
-							const uint32_t bucket = p < 32766.0f ? (uint32_t)p : 32766u, old = tq[a * TC + b];
-							if (bucket < (old & 0x7FFFu))
-								tq[a * TC + b] = (uint16_t)((old & 0x8000u) | bucket);
-						}
-					};
-					tq[t] = (uint16_t)(0x8000u | kNotQueued); // solved, not queued
-					queue(-1, 0, qN);
-					queue(1, 0, qS);
-					queue(0, -1, qW);
-					queue(0, 1, qE);
-					queue(-1, -1, qNW);
-					queue(-1, 1, qNE);
-					queue(1, -1, qSW);
-					queue(1, 1, qSE);
+				// lanes 0..7: one neighbour each (N S W E NW NE SW SE), lane 8: this tile -- nine different queue entries, one round trip
+				if (lane < 9) {
+					const int dtr = lane < 2 ? (lane == 0 ? -1 : 1) : (lane < 4 ? 0 : (lane < 6 ? -1 : (lane < 8 ? 1 : 0)));
+					const int dtc = lane < 2 ? 0 : (lane < 4 ? (lane == 2 ? -1 : 1) : (lane < 8 ? ((lane & 1) ? 1 : -1) : 0));
+					const float p = lane == 0 ? qN : lane == 1 ? qS : lane == 2 ? qW : lane == 3 ? qE : lane == 4 ? qNW : lane == 5 ? qNE : lane == 6 ? qSW : lane == 7 ? qSE : kInf;
+					const int a = tr + dtr, b = tc + dtc;
+					if (lane == 8) {
+						tq_set(t, 0x8000u | kNotQueued); // solved, not queued
+					} else if (p < kInf && a >= 0 && b >= 0 && a < TR && b < TC) {
+						const uint32_t bucket = p < 32766.0f ? (uint32_t)p : 32766u, old = tq_get(a * TC + b);
+						if (bucket < (old & 0x7FFFu))
+							tq_set(a * TC + b, (old & 0x8000u) | bucket);
+					}
 				}
 			}
 			TILE_STAMP(3) // neighbours re-queued
@@ -579,7 +609,7 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 		// ---- +inf for the tiles the wavefront never reached (heuristics.cpp:108-113)
 		if (!flagged) {
 			for (int t = 0; t < nTiles; t++) {
-				if (tq[t] & 0x8000u)
+				if (tq_get(t) & 0x8000u)
 					continue;
 				const int tr = t / TC, tc = t - tr * TC;
 				for (int u = 0; u < TW; u++) {
@@ -681,11 +711,16 @@ int tile_width()
 	return w;
 }
 
-size_t tiles_lds_bytes(int rows, int cols)
+size_t tiles_count(int rows, int cols)
 {
 	const int tw = tile_width();
-	const size_t nTiles = (size_t)((rows + TT - 1) / TT) * (size_t)((cols + tw - 1) / tw);
-	return ((size_t)(tw == 64 ? TileShape<64>::LNP : TileShape<32>::LNP) * 4 + ((nTiles + 1) & ~(size_t)1) * 2 + 15) & ~(size_t)15;
+	return (size_t)((rows + TT - 1) / TT) * (size_t)((cols + tw - 1) / tw);
+}
+
+size_t tiles_lds_bytes(int rows, int cols, bool queueInGlobal = false)
+{
+	const size_t nTiles = tiles_count(rows, cols);
+	return ((size_t)(tile_width() == 64 ? TileShape<64>::LNP : TileShape<32>::LNP) * 4 + (queueInGlobal ? 0 : ((nTiles + 1) & ~(size_t)1) * 2) + 15) & ~(size_t)15;
 }
 
 /// waves per workgroup: as many as make the workgroup's LDS exceed half of a CU's 160 KB (see k_wavefront_tiles), at most 8
@@ -705,7 +740,12 @@ int waves_per_pack(size_t ldsPerWave)
 
 void launch_tiles_kernel(hipStream_t s, int waves, TilesArgs A)
 {
-	const size_t lds = tiles_lds_bytes(A.m.rows, A.m.cols);
+	// the tile queue in global memory: where the caller brought regions for it (a pipeline on a large map, wavefront_tiles_queue_words) and nobody asked for counters
+	const bool gq = A.pub.tilesQueue && A.pub.tilesQueueWaves > 0 && !A.stats;
+	const size_t lds = tiles_lds_bytes(A.m.rows, A.m.cols, gq);
+	static const bool trace = getenv("PP_WF_TILES_TRACE") != nullptr; // tests: which instantiation ran
+	if (trace && A.nGoals > 0) // (not the warm-up launch)
+		fprintf(stderr, "[tiles] launch: %d waves, tile queue in %s\n", waves, gq ? "global memory" : "LDS");
 	// packs protect the pipeline's persistent search grid; a launch outside a pipeline has the chip to itself: single waves, eight per CU
 	const int pack = A.pub.ready ? waves_per_pack(lds) : 1;
 	// (a pack of eight waves whose slices add up to less than half a CU's LDS asks for 82 KB all the same: one pack per CU is the point)
@@ -722,25 +762,33 @@ void launch_tiles_kernel(hipStream_t s, int waves, TilesArgs A)
 		return v < 0 ? 0 : (v > 3 ? 3 : v);
 	}();
 	A.prio = prio;
+	if (gq && waves > A.pub.tilesQueueWaves / pack * pack)
+		waves = A.pub.tilesQueueWaves / pack * pack; // (a region per wave of every workgroup)
 	const int grid = (waves + pack - 1) / pack;
 	static const bool attr = [] { // a pack's dynamic LDS goes beyond the 64 KB a launch gets without asking
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<64, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<32, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<64, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<32, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<64, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wavefront_tiles<32, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		return true;
 	}();
 	(void)attr;
 	if (tile_width() == 64) {
 		if (A.stats)
-			hipLaunchKernelGGL((k_wavefront_tiles<64, true>), dim3(grid), dim3(64 * pack), packLds, s, A);
+			hipLaunchKernelGGL((k_wavefront_tiles<64, true, false>), dim3(grid), dim3(64 * pack), packLds, s, A);
+		else if (gq)
+			hipLaunchKernelGGL((k_wavefront_tiles<64, false, true>), dim3(grid), dim3(64 * pack), packLds, s, A);
 		else
-			hipLaunchKernelGGL((k_wavefront_tiles<64, false>), dim3(grid), dim3(64 * pack), packLds, s, A);
+			hipLaunchKernelGGL((k_wavefront_tiles<64, false, false>), dim3(grid), dim3(64 * pack), packLds, s, A);
 	} else {
 		if (A.stats)
-			hipLaunchKernelGGL((k_wavefront_tiles<32, true>), dim3(grid), dim3(64 * pack), packLds, s, A);
+			hipLaunchKernelGGL((k_wavefront_tiles<32, true, false>), dim3(grid), dim3(64 * pack), packLds, s, A);
+		else if (gq)
+			hipLaunchKernelGGL((k_wavefront_tiles<32, false, true>), dim3(grid), dim3(64 * pack), packLds, s, A);
 		else
-			hipLaunchKernelGGL((k_wavefront_tiles<32, false>), dim3(grid), dim3(64 * pack), packLds, s, A);
+			hipLaunchKernelGGL((k_wavefront_tiles<32, false, false>), dim3(grid), dim3(64 * pack), packLds, s, A);
 	}
 }
 
@@ -770,6 +818,20 @@ bool wavefront_tiles_supported(int rows, int cols)
 	return tiles_lds_bytes(rows, cols) <= 64 * 1024; // (dynamic LDS of a launch: packs of waves, <= 160 KB)
 }
 
+size_t wavefront_tiles_queue_words(int rows, int cols)
+{
+	// per wave of a launch; 0: the queue stays in LDS (maps up to 2048 x 2048 cells with 32-column tiles: 8 KB of queue next to 9 KB of tile).
+	// PP_WF_TILES_QUEUE=lds / global overrides.
+	static const int forced = [] {
+		const char* e = getenv("PP_WF_TILES_QUEUE");
+		return !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 'l' ? -1 : 0));
+	}();
+	const size_t nTiles = tiles_count(rows, cols);
+	if (forced < 0 || (forced == 0 && nTiles <= 4096))
+		return 0;
+	return (nTiles + 1) / 2;
+}
+
 int wavefront_tiles_resident_blocks(int rows, int cols)
 {
 	// waves of the tile form that can be resident at once: packs per CU (occupancy API) x waves per pack x CUs
@@ -779,8 +841,8 @@ int wavefront_tiles_resident_blocks(int rows, int cols)
 		return 1024;
 	const size_t lds = tiles_lds_bytes(rows, cols);
 	const int pack = 1; // (an upper bound: single-wave workgroups, launch_tiles_kernel; packs hold fewer)
-	const hipError_t e = tile_width() == 64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles<64, false>, 64 * pack, lds * pack)
-	                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles<32, false>, 64 * pack, lds * pack);
+	const hipError_t e = tile_width() == 64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles<64, false, false>, 64 * pack, lds * pack)
+	                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_wavefront_tiles<32, false, false>, 64 * pack, lds * pack);
 	if (e != hipSuccess || perCu < 1)
 		perCu = 1;
 	return perCu * pack * prop.multiProcessorCount;

@@ -122,3 +122,19 @@ def test_tile_form_switched_off():
     """PP_WF_TILES=0: every goal through the ordered kernel, same fields."""
     out = _child({"PP_WF_TILES": "0"}, "plain")
     assert "BAD 0" in out, out
+
+
+def test_tile_queue_in_global_memory_through_a_pipeline():
+    """PP_WF_TILES_QUEUE=global: a pipeline brings per-wave regions for the tile queue (what it does by itself above 2048 x 2048 cells,
+    where 16 KB of queue per wave would halve the tile waves per CU) and its launches run the instantiation that keeps the queue there.
+    The pipeline's oracle test (200 queries through 48 recycled slots: every field, every search) runs in a child process with the
+    variable set; PP_WF_TILES_QUEUE is read once per process."""
+    env = dict(os.environ)
+    env["PP_WF_TILES_QUEUE"] = "global"
+    env["PP_WF_TILES_TRACE"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_pipeline.py"), "-q", "-x", "-s", "-k",
+                        "matches_the_oracle_with_recycled_slots or replay_with_queued_launches", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1000:]
+    assert "tile queue in global memory" in r.stderr and "tile queue in LDS" not in r.stderr, r.stderr[-1000:]

@@ -40,11 +40,12 @@ def test_scratch_and_spills_do_not_regress():
         k = res[name]
         assert k["scratch_bytes_per_lane"] <= scratch, (name, k)
         assert k["vgpr_spill"] <= spills, (name, k)
-    # the tile form of the wavefront (all instantiations): no scratch at all, and few enough registers for two waves beside a 256-register search wave on a SIMD (112)
+    # the tile form of the wavefront (all instantiations): no scratch at all, and few enough registers for two waves beside a 256-register search wave on a SIMD
+    # (512 registers per lane and SIMD, allocated in blocks of eight: 256 + 2 x 128; a third wave would need <= 80)
     tiles = [k for k in kernel_resources.resources(lib) if k["kernel"].startswith("k_wavefront_tiles")]
-    assert len(tiles) >= 2
+    assert len(tiles) >= 6  # tile widths 32 / 64 x {plain, counters, queue in global memory}
     for k in tiles:
-        assert k["scratch_bytes_per_lane"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 112, k
+        assert k["scratch_bytes_per_lane"] == 0 and k["vgpr_spill"] == 0 and k["vgpr"] <= 128, k
     # the wavefront kernel must keep two workgroups of eight waves per CU: <= 128 VGPRs, <= 80 KiB LDS
     assert res["k_wavefront<false>"]["vgpr"] <= 128 and res["k_wavefront<false>"]["lds_bytes"] <= 80 * 1024
 
