@@ -355,8 +355,10 @@ int pp_planner_certify_lattice(pp_planner* planner, int32_t q, int32_t* n_checke
  * closer than twice the validator's minimum safe radius to an obstacle or to the edge of the state space -- the ones that tend to
  * exhaust the lattice and end a run -- are built ahead of the submissions queued before them (PP_PIPE_URGENT_CLEARANCE=<m>, 0 = in
  * order of submission).  Results arrive in completion order either way.
- * Not thread-safe per pipeline.  Set GPU_MAX_HW_QUEUES >= 8 before the HIP runtime starts: the pipeline's kernels run on seven
- * streams, and two streams that share a hardware queue serialise (the grid then falls back on its idle time-out, PP_PIPE_IDLE_MS). */
+ * Not thread-safe per pipeline.  Set GPU_MAX_HW_QUEUES >= 16 before the HIP runtime starts: the pipeline's long launches run on
+ * streams of their own, and two streams that share a hardware queue serialise.  pp_pipeline_create CHECKS this (an oversubscribed
+ * probe launch on every long-launch stream, a tiny kernel on every other one) and returns PP_ERR_INVALID with a message that names
+ * the variable when a stream had to wait; PP_PIPE_ALLOW_SHARED_QUEUES=1 runs regardless (idle waves then leave after PP_PIPE_IDLE_MS). */
 typedef struct pp_pipeline pp_pipeline;
 int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capacity, int32_t max_nodes_per_query, int32_t search_rows, int32_t log_expansions,
 	pp_pipeline** out);

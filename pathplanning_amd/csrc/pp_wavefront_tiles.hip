@@ -820,16 +820,14 @@ bool wavefront_tiles_supported(int rows, int cols)
 
 size_t wavefront_tiles_queue_words(int rows, int cols)
 {
-	// per wave of a launch; 0: the queue stays in LDS (maps up to 2048 x 2048 cells with 32-column tiles: 8 KB of queue next to 9 KB of tile).
-	// PP_WF_TILES_QUEUE=lds / global overrides.
-	static const int forced = [] {
+	// per wave of a launch; 0: the queue stays in LDS.  Opt-in (PP_WF_TILES_QUEUE=global): at 4096^2 -- 16 KB of queue next to 9 KB of tile, four
+	// waves per CU with it in LDS, eight without -- the stage is bound by the goals in flight that 1536 slots of 64 MB allow, not by resident
+	// waves: 732-748 plans/s with the queue in global memory, 745-765 with it in LDS (profiles/r04_packs_and_ab.txt).
+	static const bool global = [] {
 		const char* e = getenv("PP_WF_TILES_QUEUE");
-		return !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 'l' ? -1 : 0));
+		return e && e[0] == 'g';
 	}();
-	const size_t nTiles = tiles_count(rows, cols);
-	if (forced < 0 || (forced == 0 && nTiles <= 4096))
-		return 0;
-	return (nTiles + 1) / 2;
+	return global ? (tiles_count(rows, cols) + 1) / 2 : 0;
 }
 
 int wavefront_tiles_resident_blocks(int rows, int cols)
