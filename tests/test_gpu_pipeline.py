@@ -130,6 +130,49 @@ def test_pipeline_equals_the_batch_planner_and_restarts_after_idling(monkeypatch
     batch.close()
 
 
+@pytest.mark.parametrize("solo", [("50", "1000000"), ("2000", "8")])
+def test_waves_with_a_long_query_stop_claiming_and_results_stay_the_batch_planners(monkeypatch, solo):
+    """PP_PIPE_SOLO_AFTER / PP_PIPE_SOLO_BACKLOG (off by default): a wave one of whose rows has passed that many expansions takes nothing new while
+    the ready ring holds fewer fields than the backlog.  ("50", huge): nearly every wave goes solo at once and never claims beside a long query --
+    everything must still complete (a wave whose long query ends claims again) and equal the batch planner's results; ("2000", "8"): the policy as
+    it would be used, switching on and off with the ring's length."""
+    import pathplanning_amd as pa
+    monkeypatch.setenv("PP_PIPE_SOLO_AFTER", solo[0])
+    monkeypatch.setenv("PP_PIPE_SOLO_BACKLOG", solo[1])
+    w, ms, val, ctx = make_pair(512, 12, 1)
+    rng = np.random.RandomState(9)
+    n = 600
+    starts, goals = valid_random_poses(rng, w, n), valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 77
+    batch = pa.HybridAStarBatch(val, max_batch=n, max_nodes=65536, search_rows=256)
+    batch.initialize()
+    want = batch.search_batch(starts, goals, seeds)
+    pipe = pa.HybridAStarPipeline(val, capacity=256, max_nodes=65536, search_rows=64)
+    pipe.initialize(batch.nonholo_table())
+    fields = ("status", "n_expanded", "n_nodes", "n_path", "n_rng_draws", "n_rs_attempts", "n_state_checks", "n_path_checks", "n_lattice_boundary_hits")
+    index_of, nxt, got = {}, 0, {}
+    t0 = time.time()
+    while len(got) < n:
+        if nxt < n and pipe.free_slots() > 0:
+            tickets = pipe.submit(starts[nxt:n], goals[nxt:n], seeds[nxt:n])
+            for i, t in enumerate(tickets):
+                index_of[int(t)] = nxt + i
+            nxt += len(tickets)
+        tickets, res = pipe.poll(512)
+        for i, t in enumerate(tickets):
+            got[index_of[int(t)]] = res[i]
+        if not len(tickets):
+            time.sleep(0.0005)
+        assert time.time() - t0 < 300, "pipeline stalled: %d of %d results" % (len(got), n)
+    for q, r in got.items():
+        for f in fields:
+            assert getattr(r, f) == getattr(want[q], f), (q, f, getattr(r, f), getattr(want[q], f))
+        assert r.cost == want[q].cost or r.status != 0
+    assert max(r.n_expanded for r in got.values()) > int(solo[0])  # (the policy had something to act on)
+    pipe.close()
+    batch.close()
+
+
 def test_pipeline_under_dribbling_submissions_and_short_idle_timeout(monkeypatch):
     """The grid's waves leave when nothing is left to claim (or after PP_PIPE_IDLE_MS without work) and every submission launches the grid
     again: here with a 1 ms idle time-out, 8 slots, 2 waves and queries arriving one to three at a time with pauses, so that waves leave
