@@ -440,7 +440,8 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 				// ---- static masks.  Diagonal move into cell (i, j) from (i-1, j-1): blocked iff (i, j-1) and (i-1, j) are both occupied
 				const Mask occUp = mask_from_prev(occ, tH), occDn = mask_from_next(occ, bH);
 				const Mask occWst = (Mask)(occ << 1) | (Mask)occL, occEst = (Mask)(occ >> 1) | ((Mask)occR << (TW - 1));
-				const Mask aNW = ~(occUp & occWst), aNE = ~(occUp & occEst), aSW = ~(occDn & occWst), aSE = ~(occDn & occEst);
+				const Mask bNW = occUp & occWst, bNE = occUp & occEst, bSW = occDn & occWst, bSE = occDn & occEst; // blocked diagonal moves
+				const Mask aNW = ~bNW, aNE = ~bNE, aSW = ~bSW, aSE = ~bSE;
 				int k = kmin;
 				for (;;) {
 					// members of bucket k: `cur` inside the tile, halo cells by their bucket number
@@ -459,14 +460,22 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 					// A lane settles TWO of its row's candidates per pass: the sixteen LDS reads of both are in flight together, so a row that the
 					// front crosses at a flat angle (two or three candidates) costs one latency chain, not two or three.  (A candidate next to the
 					// other one may read it before or after its cost is written: either way a cost of bucket k+1 or later, never the minimum.)
-					auto settle = [&](Mask bit, uint32_t w, uint32_t e, uint32_t n, uint32_t s, uint32_t nw, uint32_t ne, uint32_t sw, uint32_t se) -> float {
+					auto settle = [&](int j, uint32_t w, uint32_t e, uint32_t n, uint32_t s, uint32_t nw, uint32_t ne, uint32_t sw, uint32_t se) -> float {
 						// costs are non-negative floats (+inf = none): their bit patterns order like the values, so the minima are integer
-						// minima (v_min3_u32; a float minimum first quiets its operands: six more instructions per candidate)
+						// minima (v_min3_u32; a float minimum first quiets its operands: six more instructions per candidate).  A blocked diagonal
+						// move becomes all ones -- above every cost, +inf included -- by OR-ing the sign-extended bit of the blocked mask (v_bfe_i32 + v_or:
+						// the and / compare / select it replaces was a quarter of a pass's instructions, with a hazard nop behind every compare)
 						const uint32_t minS = min(min(w, e), min(n, s));
-						uint32_t minD = (aNW & bit) ? nw : kInfBits;
-						minD = min(minD, (aNE & bit) ? ne : kInfBits);
-						minD = min(minD, (aSW & bit) ? sw : kInfBits);
-						minD = min(minD, (aSE & bit) ? se : kInfBits);
+						auto blocked = [&](Mask b) -> uint32_t {
+							if constexpr (sizeof(Mask) == 4)
+								return (uint32_t)__builtin_amdgcn_sbfe((int)b, (unsigned)j, 1u);
+							else
+								return (uint32_t)-(int32_t)((uint32_t)(b >> j) & 1u);
+						};
+						uint32_t minD = nw | blocked(bNW);
+						minD = min(minD, ne | blocked(bNE));
+						minD = min(minD, sw | blocked(bSW));
+						minD = min(minD, se | blocked(bSE));
 						flagged |= minS == minD; // a straight and a diagonal neighbour tie for the minimum: the pop order would decide
 						return minS <= minD ? __uint_as_float(minS) + 1.0f : __uint_as_float(minD) + kDiag; // float pathCost = transitionCost + m_cost[cell], heuristics.cpp:134-135
 					};
@@ -485,8 +494,8 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 							const uint32_t nw0 = Lu[a0 - LS - 1], ne0 = Lu[a0 - LS + 1], sw0 = Lu[a0 + LS - 1], se0 = Lu[a0 + LS + 1];
 							const uint32_t w1 = Lu[a1 - 1], e1 = Lu[a1 + 1], n1 = Lu[a1 - LS], s1 = Lu[a1 + LS];
 							const uint32_t nw1 = Lu[a1 - LS - 1], ne1 = Lu[a1 - LS + 1], sw1 = Lu[a1 + LS - 1], se1 = Lu[a1 + LS + 1];
-							const float v0 = settle(bit0, w0, e0, n0, s0, nw0, ne0, sw0, se0);
-							const float v1 = settle(bit1, w1, e1, n1, s1, nw1, ne1, sw1, se1);
+							const float v0 = settle(j0, w0, e0, n0, s0, nw0, ne0, sw0, se0);
+							const float v1 = settle(j1, w1, e1, n1, s1, nw1, ne1, sw1, se1);
 							L[a0] = v0;
 							if (two)
 								L[a1] = v1;
