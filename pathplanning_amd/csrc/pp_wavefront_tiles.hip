@@ -290,7 +290,8 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 		pendingSlot = -1;
 		if (g < 0)
 			break;
-		stGoals++;
+		if (kProf)
+			stGoals++;
 		float* const cost = A.costOut + (int64_t)g * fieldElems;
 		const int goalR = start >= 0 ? start / cols : -1, goalC = start >= 0 ? start - goalR * cols : -1;
 
@@ -434,7 +435,8 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 				a = wave_min_u32(a);
 				kmin = goalHere ? 0 : (int)a;
 			}
-			stVisits++;
+			if (kProf) // (counters exist in the instantiation that reports them: launches with A.stats; eight instructions per candidate pass otherwise)
+				stVisits++;
 			TILE_STAMP(0) // loads, LDS set-up
 			if (kmin >= 0) { // (a tile queued by a border cell that no free halo cell of it sees any more has nothing to start from)
 				// ---- static masks.  Diagonal move into cell (i, j) from (i-1, j-1): blocked iff (i, j-1) and (i-1, j) are both occupied
@@ -454,7 +456,8 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 					const Mask mNW = ((Mask)(up << 1) | (Mask)(lrU & 1u)) & aNW, mNE = ((Mask)(up >> 1) | ((Mask)(lrU >> 1) << (TW - 1))) & aNE;
 					const Mask mSW = ((Mask)(dn << 1) | (Mask)(lrD & 1u)) & aSW, mSE = ((Mask)(dn >> 1) | ((Mask)(lrD >> 1) << (TW - 1))) & aSE;
 					Mask cand = (mW | mE | up | dn | mNW | mNE | mSW | mSE) & (Mask)~closed;
-					stRounds++;
+					if (kProf)
+						stRounds++;
 					TILE_STAMP(1) // a round's masks
 					const float kNext2 = (float)(k + 2);
 					// A lane settles TWO of its row's candidates per pass: the sixteen LDS reads of both are in flight together, so a row that the
@@ -480,7 +483,8 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 						return minS <= minD ? __uint_as_float(minS) + 1.0f : __uint_as_float(minD) + kDiag; // float pathCost = transitionCost + m_cost[cell], heuristics.cpp:134-135
 					};
 					while (__ballot(cand != 0)) {
-						stPasses++;
+						if (kProf)
+							stPasses++;
 						if (cand != 0) {
 							const int j0 = (int)__builtin_ctzll((uint64_t)cand);
 							const Mask bit0 = (Mask)1 << j0;
@@ -502,7 +506,8 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 							closed |= bit0 | bit1;
 							nx1 |= (v0 < kNext2 ? bit0 : (Mask)0) | (v1 < kNext2 ? bit1 : (Mask)0);
 							nx2 |= (v0 < kNext2 ? (Mask)0 : bit0) | (v1 < kNext2 ? (Mask)0 : bit1);
-							stCells += two ? 2 : 1;
+							if (kProf)
+								stCells += two ? 2 : 1;
 						}
 						wave_sync();
 					}
@@ -634,7 +639,8 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 			flagged = true;
 		if (flagged) {
 			// not certified: the ordered kernel rebuilds this goal's field from scratch (launch_wavefront queues it behind this launch)
-			stFb++;
+			if (kProf)
+				stFb++;
 			if (lane == 0)
 				A.fbList[atomicAdd(A.ctl + 2, 1)] = g;
 			continue;
@@ -653,7 +659,7 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 			}
 		}
 	}
-	if (A.stats && lane == 0) {
+	if (kProf && A.stats && lane == 0) {
 		atomicAdd(A.stats + 0, stGoals);
 		atomicAdd(A.stats + 1, stVisits);
 		atomicAdd(A.stats + 2, stRounds);
@@ -665,7 +671,7 @@ __global__ void __launch_bounds__(512) k_wavefront_tiles(TilesArgs A)
 				atomicAdd(A.stats + 8 + i, ph[i]);
 	}
 #undef TILE_STAMP
-	if (A.stats)
+	if (kProf && A.stats)
 		atomicAdd(A.stats + 4, stCells); // (counted per lane)
 	// the last wave to leave sets the goal counter back for the stream's next launch (the number of handed-over goals stays: the
 	// ordered kernel's launch behind this one reads it and sets it back in turn)
