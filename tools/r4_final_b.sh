@@ -13,7 +13,6 @@ import json
 d=json.loads(open('$O/$name.json').read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'], d['batch_stats']['success'], d['pipeline_backlog'], d.get('cpu_baseline'))" | tee -a $O/config5.txt
 }
 c5 bench_config5 1536 "--cpu-sample 4" X=1
-c5 bench_config5_3streams_2048 2048 "--no-cpu-baseline" PP_PIPE_WF_STREAMS=3
 python -c "
 import json
 def L(f): return json.loads(open('$O/%s.json'%f).read().strip().splitlines()[-1])
