@@ -124,6 +124,15 @@ def test_tile_form_switched_off():
     assert "BAD 0" in out, out
 
 
+def test_64_column_tiles():
+    """PP_WF_TILE_WIDTH=64 (one 64-bit mask word per row; the default is 32): the other instantiation of the kernel -- its blocked-move test
+    shifts a 64-bit mask where the 32-column one uses v_bfe_i32 -- gives the same fields, plain and through the counters' instantiation."""
+    out = _child({"PP_WF_TILE_WIDTH": "64"}, "plain")
+    assert "BAD 0" in out, out
+    out = _child({"PP_WF_TILE_WIDTH": "64"}, "stats")
+    assert "BAD 0" in out and "HANDED 0 40" in out, out
+
+
 def test_tile_queue_in_global_memory_through_a_pipeline():
     """PP_WF_TILES_QUEUE=global: a pipeline brings per-wave regions for the tile queue (what it does by itself above 2048 x 2048 cells,
     where 16 KB of queue per wave would halve the tile waves per CU) and its launches run the instantiation that keeps the queue there.
