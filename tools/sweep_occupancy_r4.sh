@@ -1,5 +1,8 @@
 #!/bin/bash
 # round 4: the search grid at 3 / 4 waves per SIMD (168 / 128 VGPRs, variants built with -DPP_SEARCH_WAVES_PER_SIMD) against rows and the tile packs' LDS
+# the variant libraries are not kept: build them with
+#   PP_EXTRA_HIPCC_FLAGS=-DPP_SEARCH_WAVES_PER_SIMD=4 python tools/build_variant.py ...   (or hipcc with pathplanning_amd/build.py's FLAGS, -o pathplanning_amd/lib/variants/libpphip_w4.so;
+#   -DPP_ROWS_STATS=1 for libpphip_stats.so); PP_HIP_LIB selects the library a process loads
 O=gpurun_out/r4occ; mkdir -p $O; export TMPDIR=/tmp
 run() { # name, lib, rows, extra env...
 	local name=$1 lib=$2 rows=$3; shift 3
