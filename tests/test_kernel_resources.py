@@ -59,3 +59,25 @@ def test_planner_headroom_covers_the_largest_private_segment():
     reserve = int(re.search(r"constexpr size_t kMaxPrivateBytes = (\d+);", src).group(1))
     launched = [k for n, k in res.items() if n.startswith(("k_wavefront", "k_hybrid_search", "k_postprocess"))]
     assert launched and reserve >= max(k["scratch_bytes_per_lane"] for k in launched)
+
+
+def test_search_kernel_scratch_stays_out_of_the_expansion_path(tmp_path):
+    """What an expansion waits for is scratch traffic INSIDE its chain, not the kernel's spill count (with launch bounds of 3 / 4 waves
+    per SIMD the pop, node and children phases get 43-78 scratch loads each and the same grid runs at 17.7 / 13.4 k plans/s instead of 27.2 k).  The pipeline form's
+    listing (hipcc -S with line tables) is attributed to the phases between the kernel's own ROWS_STAMP markers (tools/isa_spill_map.py): the per-expansion phases
+    together hold 22 scratch loads and 2 stores today; the Reeds-Shepp block (0.9 % of the expansions) holds the other 300."""
+    import subprocess
+    import isa_spill_map
+    from pathplanning_amd import build
+    csrc = os.path.join(ROOT, "pathplanning_amd", "csrc")
+    listing = str(tmp_path / "planner.s")
+    flags = [f for f in build.FLAGS if f not in ("-fPIC", "-shared")]
+    subprocess.check_call([build.hipcc()] + flags + ["-gline-tables-only", "-S", "--cuda-device-only", "-o", listing, os.path.join(csrc, "pp_planner.hip")],
+                          stderr=subprocess.DEVNULL)
+    phases = isa_spill_map.phases_from_stamps(os.path.join(csrc, "pp_planner_rows.hpp"))
+    m = isa_spill_map.spill_map(listing, "k_hybrid_search_rowsILb1E", "pp_planner_rows.hpp", phases)
+    hot = ("pop+refill", "node", "children", "insertion", "node-records")
+    assert all(m[p][0] > 0 for p in hot if p != "node-records"), m  # (the attribution found the phases)
+    loads, stores = sum(m[p][1] for p in hot), sum(m[p][2] for p in hot)
+    assert loads <= 40 and stores <= 6, m
+    assert m["reeds-shepp"][1] > loads  # the spills live where they cost nothing
