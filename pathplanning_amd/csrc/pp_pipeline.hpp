@@ -195,6 +195,7 @@ struct pp_pipeline {
 	std::vector<Timed> timedFree, timedBusy;
 	double wfMs = 0, searchMs = 0, searchMaxMs = 0;
 	long long wfLaunches = 0, wfGoals = 0, searchLaunches = 0;
+	int boostAfter = 0; // PP_PIPE_BOOST_AFTER: expansions after which a query's wave runs at issue priority 3 (0 = off)
 	int soloAfter = 0, soloBacklog = 256; // PP_PIPE_SOLO_AFTER / PP_PIPE_SOLO_BACKLOG: see k_hybrid_search_rows (0 = off, the default: measured neutral, profiles/r04_solo_sweep.txt)
 	unsigned long long idleTicks = 250000ull; // idle loop passes of ~4 us: about 1 s.  (50 ms until round 4: shorter than the ~100 ms the first fields of a run take, so the
 	                                         // grid's waves left before their first work arrived and came back by the luck of the top-up launches.)  Idle waves leave at once when
@@ -317,6 +318,7 @@ PipeView pipe_view(const pp_pipeline* P)
 	v.lingerTicks = P->lingerTicks;
 	v.soloAfter = P->soloAfter;
 	v.soloBacklog = P->soloBacklog;
+	v.boostAfter = P->boostAfter;
 	v.pathHost = P->pathHost;
 	v.pathHostCap = P->pathHostCap;
 	return v;
@@ -601,6 +603,10 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 		if (v && *v) {
 			const long ms = strtol(v, nullptr, 10);
 			P->idleTicks = (unsigned long long)(ms < 1 ? 1 : (ms > 10000 ? 10000 : ms)) * 250ull;
+		}
+		if (const char* ba = getenv("PP_PIPE_BOOST_AFTER")) {
+			const long x = strtol(ba, nullptr, 10);
+			P->boostAfter = x < 0 ? 0 : (x > 0x7FFFFFFF ? 0x7FFFFFFF : (int)x);
 		}
 		if (const char* sa = getenv("PP_PIPE_SOLO_AFTER")) {
 			const long x = strtol(sa, nullptr, 10);

@@ -1181,6 +1181,7 @@ struct PipeView {
 	unsigned long long idleTicks = 0; // loop passes (~4 us each: a sleep and three polls) a wave waits without work before it leaves on its own
 	int soloAfter = 0;                // > 0: a wave one of whose rows has passed this many expansions takes no new queries while the ready ring holds fewer than soloBacklog
 	int soloBacklog = 0;
+	int boostAfter = 0;               // > 0: a wave one of whose rows has passed this many expansions runs at issue priority 3 (the run's longest chains share their SIMDs with throughput work)
 };
 
 #include "pp_planner_rows.hpp"

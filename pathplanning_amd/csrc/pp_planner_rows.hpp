@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the previous owner's last stores to the rows' buffers
 	}
 	int idleIters = 0; // (wave-uniform) consecutive loop passes with every row idle
+	bool boosted = false; // (wave-uniform, pipeline) the wave runs at issue priority 3: it hosts a query past pipe.boostAfter expansions
 	unsigned passCount = 0; // (wave-uniform, pipeline) loop passes: a row that found the ring empty looks again every kPollEvery-th pass only
 	bool pollNow = true;    // (pipeline) this row looks at the ring on the next pass whatever the pass count (it has just finished a query, or lost a race)
 	int slot = waveIdx * kRowsPerWave + (lane >> 4);
@@ -392,6 +393,18 @@ __global__ void __launch_bounds__(64 * PP_ROWS_WAVES_PER_WG, PP_SEARCH_WAVES_PER
 		// ready ring is short -- rows are idle then anyway (the wavefront stage paces the pipeline), and these are the ones that should be.  With a
 		// backlog of soloBacklog fields or more every row claims as before.
 		const bool waveLong = piped && pipe.soloAfter > 0 && __ballot(act && nExpanded >= pipe.soloAfter) != 0ull;
+		// (pipeline) the same queries from the other side: their chains run at ~13 us per expansion on an empty chip and at ~22 us next to the tile waves and the other
+		// search waves of a full one; a wave that hosts one asks for the SIMD's issue slots first (s_setprio 3) until the query ends
+		if (piped && pipe.boostAfter > 0) {
+			const bool hot = __ballot(act && nExpanded >= pipe.boostAfter) != 0ull;
+			if (hot != boosted) {
+				boosted = hot;
+				if (hot)
+					__builtin_amdgcn_s_setprio(3);
+				else
+					__builtin_amdgcn_s_setprio(PP_ROWS_PRIO);
+			}
+		}
 		// ================= rows without a query take the next one =================
 		if (!act && !done) {
 			bool none = false;
