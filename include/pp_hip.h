@@ -364,7 +364,10 @@ int pp_pipeline_create(pp_map* map, const pp_hybrid_params* params, int32_t capa
 	pp_pipeline** out);
 int pp_pipeline_destroy(pp_pipeline* pipeline);
 /* Takes up to n_queries queries (as many as there are free slots: *n_accepted; submit the rest after a poll has released slots).
- * tickets_out (may be NULL): one id per accepted query, in input order.  The input arrays are free when the call returns. */
+ * tickets_out (may be NULL): one id per accepted query, in input order.  The input arrays are free when the call returns.
+ * The map as the kernels see it (bounds, grid pointers, pp_map_set_validator's tunables) is fixed per launch of the persistent search grid: a
+ * submission after it changed is refused (PP_ERR_INVALID) while queries are in flight and accepted once they have been polled (the old grid's
+ * waves are waited for).  Changing the CONTENTS of the map's grids with queries in flight is the caller's to avoid. */
 int pp_pipeline_submit_dev(pp_pipeline* pipeline, int32_t n_queries, const double* starts_dev, const double* goals_dev, const uint64_t* seeds_dev, uint64_t* tickets_out,
 	int32_t* n_accepted);
 int pp_pipeline_submit(pp_pipeline* pipeline, int32_t n_queries, const double* starts_host, const double* goals_host, const uint64_t* seeds_host, uint64_t* tickets_out,

@@ -23,6 +23,7 @@
 #pragma once
 
 #include <chrono>
+#include <cstring>
 #include <deque>
 #include <unordered_map>
 
@@ -195,6 +196,8 @@ struct pp_pipeline {
 	std::vector<Timed> timedFree, timedBusy;
 	double wfMs = 0, searchMs = 0, searchMaxMs = 0;
 	long long wfLaunches = 0, wfGoals = 0, searchLaunches = 0;
+	ppd::MapView lastView {}; // the map view of the last submission (see pp_pipeline_submit_dev)
+	bool viewValid = false;
 	int boostAfter = 0; // PP_PIPE_BOOST_AFTER: expansions after which a query's wave runs at issue priority 3 (0 = off)
 	int soloAfter = 0, soloBacklog = 256; // PP_PIPE_SOLO_AFTER / PP_PIPE_SOLO_BACKLOG: see k_hybrid_search_rows (0 = off, the default: measured neutral, profiles/r04_solo_sweep.txt)
 	unsigned long long idleTicks = 250000ull; // idle loop passes of ~4 us: about 1 s.  (50 ms until round 4: shorter than the ~100 ms the first fields of a run take, so the
@@ -674,6 +677,28 @@ int pp_pipeline_submit_dev(pp_pipeline* P, int32_t n_queries, const double* star
 		k = (int)(P->slotListCap / 4);
 	if (k == 0)
 		return PP_OK;
+	// ---- the map as the kernels see it (MapView: pointers, bounds, the validator's tunables) is a launch argument: the persistent grid's waves keep the
+	// view they were launched with.  A view that changed since the last submission (pp_map_set_validator, a rebuilt grid) must not meet queries in flight --
+	// some would be searched under the old view, some under the new one -- and with none in flight the old grid's waves are waited for first: they leave as
+	// soon as they have seen that everything was polled.
+	{
+		const ppd::MapView now = pl->map->view();
+		const ppd::MapView& was = P->lastView;
+		const bool same = now.rows == was.rows && now.cols == was.cols && now.res == was.res && now.invRes == was.invRes && now.gx == was.gx && now.gy == was.gy && now.lox == was.lox &&
+			now.loy == was.loy && now.lbx == was.lbx && now.lby == was.lby && now.lbt == was.lbt && now.ubx == was.ubx && now.uby == was.uby && now.ubt == was.ubt &&
+			now.minSafeRadius == was.minSafeRadius && now.minInterp == was.minInterp && now.dist == was.dist && now.pathcost == was.pathcost && now.occ8 == was.occ8 &&
+			now.validBits == was.validBits; // (field by field: the struct has padding)
+		if (P->viewValid && !same) {
+			if (P->nSubmitted != P->doneHead) {
+				set_error("the map's view (validator tunables, grids) changed while " + std::to_string(P->nSubmitted - P->doneHead) + " queries of this pipeline are in flight: poll them first");
+				return PP_ERR_INVALID;
+			}
+			for (int i = 0; i < kPipeSearchStreams; i++)
+				PP_HIP_TRY(hipStreamSynchronize(P->searchStream[i]));
+		}
+		P->lastView = now;
+		P->viewValid = true;
+	}
 	// ---- slots and tickets
 	if (P->slotListPos + (size_t)k > P->slotListCap)
 		P->slotListPos = 0; // (a segment never wraps)

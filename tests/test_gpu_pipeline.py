@@ -327,3 +327,41 @@ def test_held_slots_post_process_like_the_batch_planner_and_the_buffer_set_refus
     pipe.release(tickets)
     batch.close()
     pipe.close()
+
+
+def test_a_changed_validator_meets_no_query_in_flight():
+    """The map as the kernels see it (bounds, grids, the validator's tunables) is a launch argument, and the persistent grid's waves keep the one they were
+    launched with: a submission after `min_safe_radius` changed is refused while queries are in flight (some would be searched under the old radius, some
+    under the new one) and accepted once they are polled -- the old grid's waves are waited for first -- with the results of a batch planner made after
+    the change."""
+    import pathplanning_amd as pa
+    w, ms, val, ctx = make_pair(256, 6, 3)
+    rng = np.random.RandomState(21)
+    n = 96
+    starts, goals = valid_random_poses(rng, w, n), valid_random_poses(rng, w, n)
+    seeds = np.arange(n, dtype=np.uint64) + 5
+    pipe = pa.HybridAStarPipeline(val, capacity=128, max_nodes=32768, search_rows=16)
+    pipe.initialize()
+    table = pipe.nonholo_table()
+    t1 = pipe.submit(starts[:48], goals[:48], seeds[:48])
+    assert len(t1) == 48
+    old_radius = val.min_safe_radius
+    val.min_safe_radius = old_radius * 0.8
+    with pytest.raises(pa.PPError, match="in flight"):
+        pipe.submit(starts[48:], goals[48:], seeds[48:])
+    assert pipe.in_flight() == 48  # (nothing was taken by the refused call)
+    val.min_safe_radius = old_radius
+    drain(pipe, 48)
+    val.min_safe_radius = old_radius * 0.8
+    t2 = pipe.submit(starts[48:], goals[48:], seeds[48:])
+    assert len(t2) == 48
+    got = drain(pipe, 48)
+    batch = pa.HybridAStarBatch(val, max_batch=48, max_nodes=32768, search_rows=16)
+    batch.initialize(table)
+    want = batch.search_batch(starts[48:], goals[48:], seeds[48:])
+    for i, t in enumerate(t2):
+        r = got[int(t)]
+        assert (r.status, r.n_expanded, r.n_nodes, r.n_state_checks) == (want[i].status, want[i].n_expanded, want[i].n_nodes, want[i].n_state_checks), i
+    val.min_safe_radius = old_radius
+    pipe.close()
+    batch.close()
